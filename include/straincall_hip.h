@@ -1,0 +1,116 @@
+/* C-ABI of libstraincall_hip.so -- the MI355X (gfx950) implementation of the
+ * StrainCall hot path of homopolymer/RAMBL.
+ *
+ * The reference exposes this path only as a process (StrainCall argv -> FASTA on
+ * stdout, /root/reference/StrainCall/StrainCall.cpp:972-1059, launched per region
+ * by /root/reference/scripts/rambl.py:169-201).  Inside that process the path is
+ * the sequence
+ *
+ *     PartialOrderGraph(gene_seq, reads)          StrainCall.cpp:1017
+ *     pog->infer_strains(strains, read_pairs, 5000, e, tau, diff)   :1021
+ *     pog->read_assign(strains, reads, read_pairs, 5000)            :1024
+ *     sort by abundance, print                     :1027-1046
+ *     pog->output_edge(cout)   (with -G)           :1050
+ *
+ * and this library is the drop-in for exactly that sequence: the caller (the
+ * Python entry point rambl_amd/cli.py, or a cgo/JNI/ctypes binding written by a
+ * maintainer) hands over what load_gene_seq and
+ * load_mapping_reads produced (StrainCall.cpp:157-185, :480-670) as plain
+ * arrays and receives strains, abundances, the -G dump and the per-level trace.
+ *
+ * Conventions: the caller owns every buffer; every function returns 0 on success
+ * or a negative SC_ERR_* code and never throws; a context is bound to one HIP
+ * device; sc_roi_submit may be called from one host thread at a time, the regions
+ * run on `stream_count` worker threads, each with its own HIP stream.
+ * There is no CPU fallback: if no gfx950 device is present sc_ctx_create fails.
+ */
+#ifndef STRAINCALL_HIP_H
+#define STRAINCALL_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_OK 0
+#define SC_ERR_NO_DEVICE (-1)     /* no HIP device / wrong architecture */
+#define SC_ERR_HIP (-2)           /* a HIP runtime call failed (see sc_last_error) */
+#define SC_ERR_ARG (-3)           /* invalid argument / unknown handle */
+#define SC_ERR_UNSUPPORTED (-4)   /* graph shape outside the device model (message in sc_last_error) */
+#define SC_ERR_CAPACITY (-5)      /* caller buffer too small, or more than 128 live candidates */
+#define SC_ERR_INTERNAL (-6)
+
+typedef struct sc_ctx sc_ctx;
+
+/* sc_parameter fields that reach the path (StrainCall.cpp:58-95) plus the three
+ * literals of the reference's call sites (:1021,:1024 n=5000; budget 40000 at
+ * NonparametricClustering.cpp:160,781; candidate cap 80 at :532). */
+typedef struct sc_params {
+    float error_rate;      /* -e */
+    float tau;             /* -t */
+    float diff_rate;       /* -d */
+    int sweeps_cap;        /* 5000 */
+    int draw_budget;       /* 40000 */
+    int max_candidates;    /* 80 */
+    int graph_only;        /* -G: build + dump the graph, no clustering */
+    int want_trace;        /* keep the per-level strain/abundance trace */
+} sc_params;
+
+typedef struct sc_stats {
+    double graph_ms;          /* host graph build + flatten + upload */
+    double cluster_ms;        /* level walk incl. kernels */
+    double sampler_kernel_ms; /* sum of HIP-event times of the SAMPLE-mode launches */
+    long sampler_launches;
+    long level_launches;
+    long draws;               /* categorical draws made on the device */
+    long exact_draws;         /* of which resolved by the literal fp64 path */
+    long msa_calls;
+    int n_nodes, n_levels, n_unique_reads;
+    long n_read_copies;
+} sc_stats;
+
+/* Replaces process start-up; `device` is a HIP ordinal, `stream_count` the number
+ * of regions in flight.  Fails with SC_ERR_NO_DEVICE when there is no GPU. */
+int sc_ctx_create(int device, int stream_count, sc_ctx** ctx_out);
+void sc_ctx_destroy(sc_ctx* ctx);
+const char* sc_last_error(sc_ctx* ctx);
+
+/* Replaces `new PartialOrderGraph(gene_seq, reads)` + infer_strains + read_assign
+ * + the sort (StrainCall.cpp:1017-1027).
+ *   ref_bases[ref_len]            window substring of the gene (load_gene_seq)
+ *   read_pos[i]                   0-based offset in the window (AlignRead<0>)
+ *   cigar_text/cigar_off[n+1]     cropped CIGAR strings (AlignRead<1>)
+ *   seq_text/seq_off[n+1]         cropped read bases (AlignRead<2>)
+ *   read_copies[i]                copy number (AlignRead<4>)
+ *   mate_idx/mate_off[n+1]        ReadPairs: mate uid (or -1) per copy of read i
+ * Reads must be in the order load_mapping_reads emits them (StrainCall.cpp:610). */
+int sc_roi_submit(sc_ctx* ctx, const char* ref_bases, int ref_len, const int* read_pos, const char* cigar_text,
+                  const int* cigar_off, const char* seq_text, const int* seq_off, const int* read_copies,
+                  const int* mate_idx, const int* mate_off, int n_reads, const sc_params* params, int* handle_out);
+int sc_roi_wait(sc_ctx* ctx, int handle);
+
+/* Strains in output order (abundance descending, libstdc++ sort order for ties,
+ * StrainCall.cpp:1027).  seq_buf receives the ungapped sequences back to back
+ * (Strain::plain_seq), seq_off[n_strains+1] their offsets. */
+int sc_roi_result(sc_ctx* ctx, int handle, char* seq_buf, long seq_cap, int* seq_off, double* abundance,
+                  int max_strains, int* n_strains);
+/* Replaces pog->output_edge(cout) (PartialOrderGraph.cpp:318-337). */
+int sc_roi_graph_dump(sc_ctx* ctx, int handle, char* buf, long cap, long* len_out);
+/* Text of the reference's dormant debug blocks (NonparametricClustering.cpp:287-298,
+ * :460-471), abundances printed with %.17g. */
+int sc_roi_trace(sc_ctx* ctx, int handle, char* buf, long cap, long* len_out);
+int sc_roi_stats(sc_ctx* ctx, int handle, sc_stats* out);
+int sc_roi_release(sc_ctx* ctx, int handle);
+
+/* Row a7 on its own: MultipleSequenceAlignmentSP<...>::align + MSA<>::get
+ * (MultipleSequenceAlignmentSP.cpp:10-49, MultipleSequenceAlignment.hpp:59-70).
+ * rows_out receives n rows of (*ncol_out) characters + NUL, back to back. */
+int sc_msa_align(sc_ctx* ctx, const char* seq_text, const int* seq_off, int n, char* rows_out, long cap, int* ncol_out);
+
+/* Row a16 on its own: number_of_reads_cover_nodes for every edge of a region
+ * (PartialOrderGraph.cpp:1218-1244), in the edge order of the -G dump. */
+int sc_roi_edge_support(sc_ctx* ctx, int handle, int* support, int cap, int* n_edges);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -65,6 +65,22 @@ int oracle_main(int argc, char **argv) {
         AReadVec reads; vec_init(reads);
         ReadPairs rp; rp.mates = NULL; rp.n = 0;
         load_mapping_reads(gene_seq, pa.mapping_file, pa.mapping_qual, pa.read_len, pa.max_ins, pa.max_depth, roi, &reads, &rp);
+        if (getenv("SC_ORACLE_DUMP_READS")) {
+            /* test fixture: what crosses from ingest (a1-a4) into the graph stage */
+            char path[4096];
+            snprintf(path, sizeof path, "%s.%d", getenv("SC_ORACLE_DUMP_READS"), wi);
+            FILE *df = fopen(path, "w");
+            if (df) {
+                fprintf(df, "WINDOW\t%s\t%d\t%d\n", w->gn, w->p0, w->p1);
+                fprintf(df, "REF\t%s\n", gene_seq);
+                for (int i = 0; i < reads.n; i++) {
+                    fprintf(df, "READ\t%d\t%s\t%s\t%d\t", reads.v[i].pos, reads.v[i].cigar, reads.v[i].seq, reads.v[i].cn);
+                    for (int k = 0; k < rp.mates[i].n; k++) fprintf(df, "%s%d", k ? "," : "", rp.mates[i].v[k]);
+                    fprintf(df, "\n");
+                }
+                fclose(df);
+            }
+        }
         if (reads.n == 0) { free(gene_seq); continue; }
         Graph *g = graph_build(gene_seq, reads.v, reads.n);
         if (!pa.plot_graph) {

@@ -1,0 +1,204 @@
+"""ctypes binding of libstraincall_hip.so (include/straincall_hip.h).
+
+There is no CPU fallback: importing this module fails loudly when the HIP
+library has not been built, and `Context()` fails when no gfx950 device exists.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstraincall_hip.so")
+
+SC_OK = 0
+ERRORS = {-1: "SC_ERR_NO_DEVICE", -2: "SC_ERR_HIP", -3: "SC_ERR_ARG", -4: "SC_ERR_UNSUPPORTED",
+          -5: "SC_ERR_CAPACITY", -6: "SC_ERR_INTERNAL"}
+
+
+class ScParams(C.Structure):
+    _fields_ = [("error_rate", C.c_float), ("tau", C.c_float), ("diff_rate", C.c_float),
+                ("sweeps_cap", C.c_int), ("draw_budget", C.c_int), ("max_candidates", C.c_int),
+                ("graph_only", C.c_int), ("want_trace", C.c_int)]
+
+
+class ScStats(C.Structure):
+    _fields_ = [("graph_ms", C.c_double), ("cluster_ms", C.c_double), ("sampler_kernel_ms", C.c_double),
+                ("sampler_launches", C.c_long), ("level_launches", C.c_long), ("draws", C.c_long),
+                ("exact_draws", C.c_long), ("msa_calls", C.c_long), ("n_nodes", C.c_int), ("n_levels", C.c_int),
+                ("n_unique_reads", C.c_int), ("n_read_copies", C.c_long)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class StrainCallError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("%s (%d)%s" % (ERRORS.get(code, "error"), code, (": " + msg) if msg else ""))
+        self.code = code
+
+
+def load_library():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback for the StrainCall path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, cp = C.c_void_p, C.POINTER(C.c_int), C.c_char_p
+    lib.sc_ctx_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    lib.sc_ctx_destroy.argtypes = [vp]
+    lib.sc_ctx_destroy.restype = None
+    lib.sc_last_error.argtypes = [vp]
+    lib.sc_last_error.restype = cp
+    lib.sc_roi_submit.argtypes = [vp, cp, C.c_int, ip, cp, ip, cp, ip, ip, ip, ip, C.c_int, C.POINTER(ScParams), ip]
+    lib.sc_roi_wait.argtypes = [vp, C.c_int]
+    lib.sc_roi_result.argtypes = [vp, C.c_int, C.c_char_p, C.c_long, ip, C.POINTER(C.c_double), C.c_int, ip]
+    lib.sc_roi_graph_dump.argtypes = [vp, C.c_int, C.c_char_p, C.c_long, C.POINTER(C.c_long)]
+    lib.sc_roi_trace.argtypes = [vp, C.c_int, C.c_char_p, C.c_long, C.POINTER(C.c_long)]
+    lib.sc_roi_stats.argtypes = [vp, C.c_int, C.POINTER(ScStats)]
+    lib.sc_roi_release.argtypes = [vp, C.c_int]
+    lib.sc_roi_edge_support.argtypes = [vp, C.c_int, ip, C.c_int, ip]
+    lib.sc_msa_align.argtypes = [vp, cp, ip, C.c_int, C.c_char_p, C.c_long, ip]
+    for f in ("sc_ctx_create", "sc_roi_submit", "sc_roi_wait", "sc_roi_result", "sc_roi_graph_dump", "sc_roi_trace",
+              "sc_roi_stats", "sc_roi_release", "sc_roi_edge_support", "sc_msa_align"):
+        getattr(lib, f).restype = C.c_int
+    return lib
+
+
+EXPORTS = ["sc_ctx_create", "sc_ctx_destroy", "sc_last_error", "sc_roi_submit", "sc_roi_wait", "sc_roi_result",
+           "sc_roi_graph_dump", "sc_roi_trace", "sc_roi_stats", "sc_roi_release", "sc_roi_edge_support", "sc_msa_align"]
+
+
+def default_params(error_rate=0.01, tau=0.02, diff_rate=0.01, graph_only=False, want_trace=False):
+    return ScParams(error_rate, tau, diff_rate, 5000, 40000, 80, int(graph_only), int(want_trace))
+
+
+def _pack(strings):
+    off = (C.c_int * (len(strings) + 1))()
+    n = 0
+    for i, s in enumerate(strings):
+        off[i] = n
+        n += len(s)
+    off[len(strings)] = n
+    return "".join(strings).encode("ascii"), off
+
+
+class RegionResult:
+    def __init__(self, seqs, abundance, graph, trace, stats):
+        self.seqs = seqs
+        self.abundance = abundance
+        self.graph = graph
+        self.trace = trace
+        self.stats = stats
+
+
+class Context:
+    """One HIP device, `streams` regions in flight."""
+
+    def __init__(self, device=0, streams=1):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.sc_ctx_create(device, streams, C.byref(self.h))
+        if rc != SC_OK:
+            raise StrainCallError(rc, "no gfx950 HIP device %d (the StrainCall path has no CPU fallback)" % device)
+
+    def close(self):
+        if self.h:
+            self.lib.sc_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _err(self, rc):
+        msg = self.lib.sc_last_error(self.h)
+        return StrainCallError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+    def submit(self, region, params):
+        """region: ingest.RegionReads.  Returns a handle."""
+        n = len(region)
+        pos = (C.c_int * max(n, 1))(*region.pos)
+        cn = (C.c_int * max(n, 1))(*region.copies)
+        cig, cig_off = _pack(region.cigar)
+        seq, seq_off = _pack(region.seq)
+        mate_off = (C.c_int * (n + 1))()
+        flat = []
+        for i, m in enumerate(region.mates):
+            mate_off[i] = len(flat)
+            flat.extend(m)
+        mate_off[n] = len(flat)
+        mate_idx = (C.c_int * max(len(flat), 1))(*flat)
+        ref = region.gene_seq.encode("ascii")
+        handle = C.c_int()
+        rc = self.lib.sc_roi_submit(self.h, ref, len(ref), pos, cig, cig_off, seq, seq_off, cn, mate_idx, mate_off, n,
+                                    C.byref(params), C.byref(handle))
+        if rc != SC_OK:
+            raise self._err(rc)
+        return handle.value
+
+    def wait(self, handle, want_graph=False, want_trace=False, release=True):
+        rc = self.lib.sc_roi_wait(self.h, handle)
+        graph = trace = None
+        stats = ScStats()
+        self.lib.sc_roi_stats(self.h, handle, C.byref(stats))
+        if want_graph or rc != SC_OK:
+            ln = C.c_long()
+            self.lib.sc_roi_graph_dump(self.h, handle, None, 0, C.byref(ln))
+            buf = C.create_string_buffer(ln.value + 1)
+            if self.lib.sc_roi_graph_dump(self.h, handle, buf, ln.value, C.byref(ln)) == SC_OK:
+                graph = buf.raw[:ln.value].decode("ascii")
+        if rc != SC_OK:
+            err = self._err(rc)
+            if release:
+                self.lib.sc_roi_release(self.h, handle)
+            err.graph = graph
+            raise err
+        nst = C.c_int()
+        cap, maxs = 1 << 16, 256
+        while True:
+            buf = C.create_string_buffer(cap)
+            off = (C.c_int * (maxs + 1))()
+            ab = (C.c_double * maxs)()
+            rc = self.lib.sc_roi_result(self.h, handle, buf, cap, off, ab, maxs, C.byref(nst))
+            if rc == -5 and cap < (1 << 30):
+                cap *= 8
+                maxs *= 4
+                continue
+            break
+        if rc != SC_OK:
+            raise self._err(rc)
+        seqs = [buf.raw[off[i]:off[i + 1]].decode("ascii") for i in range(nst.value)]
+        abundance = [ab[i] for i in range(nst.value)]
+        if want_trace:
+            ln = C.c_long()
+            self.lib.sc_roi_trace(self.h, handle, None, 0, C.byref(ln))
+            tb = C.create_string_buffer(ln.value + 1)
+            if self.lib.sc_roi_trace(self.h, handle, tb, ln.value, C.byref(ln)) == SC_OK:
+                trace = tb.raw[:ln.value].decode("ascii")
+        if release:
+            self.lib.sc_roi_release(self.h, handle)
+        return RegionResult(seqs, abundance, graph, trace, stats.as_dict())
+
+    def run(self, region, params, want_graph=False, want_trace=False):
+        return self.wait(self.submit(region, params), want_graph, want_trace)
+
+    def edge_support(self, handle):
+        n = C.c_int()
+        self.lib.sc_roi_edge_support(self.h, handle, None, 0, C.byref(n))
+        arr = (C.c_int * max(n.value, 1))()
+        rc = self.lib.sc_roi_edge_support(self.h, handle, arr, n.value, C.byref(n))
+        if rc != SC_OK:
+            raise self._err(rc)
+        return list(arr[:n.value])
+
+    def msa_align(self, seqs):
+        """Row a7: rows of the progressive sum-of-pairs MSA of `seqs` (in the given order)."""
+        txt, off = _pack(seqs)
+        cap = (len(txt) + 2) * max(len(seqs), 1) + 16
+        out = C.create_string_buffer(cap)
+        ncol = C.c_int()
+        rc = self.lib.sc_msa_align(self.h, txt, off, len(seqs), out, cap, C.byref(ncol))
+        if rc != SC_OK:
+            raise self._err(rc)
+        w = ncol.value + 1
+        return [out.raw[i * w:i * w + ncol.value].decode("ascii") for i in range(len(seqs))]

@@ -1,0 +1,886 @@
+// Host driver + C-ABI of libstraincall_hip.so.  See include/straincall_hip.h.
+//
+// Per region: build the partial order graph (sc_graph.cpp; the insertion MSA runs
+// on the device through k_msa), flatten it level-major, upload it once, compute
+// every edge support on the device (k_edge_support), then walk the levels of
+// /root/reference/StrainCall/NonparametricClustering.cpp:262-582.  The walk keeps
+// only the scalar bookkeeping of the candidate strains on the host (6x6 models,
+// abundances, pruning / extension decisions); the per-read work of every level --
+// log-likelihood update, soft update, Polya-urn sampler -- is one k_level launch
+// on the region's stream, and the per-strain read log-likelihood rows never leave
+// HBM.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/straincall_hip.h"
+#include "sc_device.hpp"
+#include "sc_graph.hpp"
+
+namespace sc {
+
+// launchers defined in sc_kernels.hip
+void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node, const int* pool_ptr, const int* pool_rid,
+                         const int* pool_cn, const uint8_t* node_is_end, const int* edge_src, int n_edges, int sorted,
+                         int* support);
+void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int do_update);
+void launch_msa(hipStream_t st, const MsaDev& d);
+int init_kernels();
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct ScError : std::runtime_error {
+    int code;
+    ScError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw HipError(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// growable device buffer
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    void* ensure(size_t n) {
+        if (n > cap) {
+            if (p) (void)hipFree(p);
+            size_t want = n + n / 4 + 256;
+            HIPCHK(hipMalloc(&p, want));
+            cap = want;
+        }
+        return p;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+template <class T> static T* upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) {
+    T* d = (T*)b.ensure(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (!v.empty()) HIPCHK(hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    return d;
+}
+
+// mt19937(1234) -> generate_canonical<double,53>: the stream every sampler call
+// of the reference starts from (NonparametricClustering.cpp:142,785)
+static std::vector<double> uniform_stream(unsigned seed, int n) {
+    std::vector<uint32_t> x(624);
+    x[0] = seed;
+    for (int i = 1; i < 624; i++) x[i] = 1812433253u * (x[i - 1] ^ (x[i - 1] >> 30)) + (uint32_t)i;
+    int p = 624;
+    auto next = [&]() -> uint32_t {
+        if (p >= 624) {
+            const uint32_t UP = 0x80000000u, LO = 0x7fffffffu;
+            for (int k = 0; k < 624 - 397; ++k) { uint32_t y = (x[k] & UP) | (x[k + 1] & LO); x[k] = x[k + 397] ^ (y >> 1) ^ ((y & 1) ? 0x9908b0dfu : 0); }
+            for (int k = 624 - 397; k < 623; ++k) { uint32_t y = (x[k] & UP) | (x[k + 1] & LO); x[k] = x[k + (397 - 624)] ^ (y >> 1) ^ ((y & 1) ? 0x9908b0dfu : 0); }
+            uint32_t y = (x[623] & UP) | (x[0] & LO);
+            x[623] = x[396] ^ (y >> 1) ^ ((y & 1) ? 0x9908b0dfu : 0);
+            p = 0;
+        }
+        uint32_t z = x[p++];
+        z ^= (z >> 11); z ^= (z << 7) & 0x9d2c5680u; z ^= (z << 15) & 0xefc60000u; z ^= (z >> 18);
+        return z;
+    };
+    std::vector<double> u(n);
+    for (int i = 0; i < n; i++) {
+        double sum = 0.0, tmp = 1.0;
+        for (int k = 2; k != 0; --k) { sum += (double)next() * tmp; tmp *= 4294967296.0; }
+        double r = sum / tmp;
+        if (r >= 1.0) r = std::nextafter(1.0, 0.0);
+        u[i] = r;
+    }
+    return u;
+}
+
+// ---------------------------------------------------------------------------
+struct Job {
+    int handle = 0;
+    // inputs
+    std::string ref;
+    std::vector<AlignedRead> reads;
+    std::vector<int> mate_off, mate_idx;
+    sc_params params{};
+    // outputs
+    std::vector<std::string> seqs;
+    std::vector<double> abund;
+    std::string graph_dump, trace;
+    std::vector<int> edge_support;
+    sc_stats stats{};
+    int status = 0;       // 0 queued/running, 1 done
+    int rc = SC_OK;
+    std::string err;
+};
+
+struct HStrain {                      // host bookkeeping of one candidate (Strain, PartialOrderGraph.hpp:362-402)
+    double sub[KK];                   // sub_count over the symbol table
+    double comp[6]; double Z;
+    double abundance;
+    int slot;                         // row of the device read_loglik matrix
+    int tail;                         // path arena index
+    int node;                         // last node of the path
+    uint64_t hash; int seqlen;        // rolling hash / length of strain_seq()
+};
+struct PathRec { int node, parent; };
+
+struct Worker;
+struct Ctx {
+    int device = 0;
+    std::string last_error;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::deque<std::shared_ptr<Job>> queue;
+    std::map<int, std::shared_ptr<Job>> jobs;
+    int next_handle = 1;
+    bool stop = false;
+    std::vector<std::unique_ptr<Worker>> workers;
+    double* dU = nullptr;             // uniform stream on the device
+};
+
+struct Worker {
+    Ctx* ctx;
+    std::thread th;
+    hipStream_t st = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    LevelParams* Ph = nullptr;        // pinned staging
+    LevelParams* Pd = nullptr;
+    LevelResult* Rh = nullptr;        // host-mapped, written by the kernel
+    LevelResult* Rd = nullptr;
+    DevBuf b_ent_rid, b_ent_cn, b_ent_lab_off, b_ent_lab_len, b_ent_first, b_ent_qoff, b_labels, b_mate_ptr, b_mate_idx,
+        b_ll, b_has, b_isnew, b_tabA, b_tabL, b_qflag, b_qcode, b_qent, b_quid, b_out_ptr, b_out_node, b_pool_ptr, b_pool_rid,
+        b_pool_cn, b_isend, b_esrc, b_support;
+    DevBuf m_seqs, m_off, m_cols0, m_cols1, m_counts, m_moves, m_trace, m_out;
+
+    void init();
+    void run();
+    void process(Job& job);
+    int msa_device(const std::vector<std::string>& seqs, std::vector<std::string>& rows);
+    void cluster(Job& job, const PoGraph& g, FlatGraph& f);
+};
+
+void Worker::init() {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&ev0));
+    HIPCHK(hipEventCreate(&ev1));
+    HIPCHK(hipHostMalloc((void**)&Ph, sizeof(LevelParams), hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&Pd, sizeof(LevelParams)));
+    HIPCHK(hipHostMalloc((void**)&Rh, sizeof(LevelResult), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&Rd, Rh, 0));
+}
+
+// a7 on the device.  Returns the number of columns.
+int Worker::msa_device(const std::vector<std::string>& seqs, std::vector<std::string>& rows) {
+    const int n = (int)seqs.size();
+    std::vector<int> off(n + 1, 0);
+    std::string packed;
+    for (int i = 0; i < n; i++) { packed += seqs[i]; off[i + 1] = (int)packed.size(); }
+    const int cmax = (int)packed.size() + 1;
+    for (int i = 1; i < n; i++)
+        if (seqs[i].size() > 63) throw ScError(SC_ERR_UNSUPPORTED, "insertion longer than 63 bases in the MSA");
+    MsaDev d;
+    char* dseq = (char*)m_seqs.ensure(packed.size() + 1);
+    int* doff = (int*)m_off.ensure(sizeof(int) * (n + 1));
+    HIPCHK(hipMemcpyAsync(dseq, packed.data(), packed.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(doff, off.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, st));
+    d.seqs = dseq; d.seq_off = doff; d.n = n; d.cmax = cmax;
+    d.cols[0] = (char*)m_cols0.ensure((size_t)cmax * n);
+    d.cols[1] = (char*)m_cols1.ensure((size_t)cmax * n);
+    d.counts = (int*)m_counts.ensure(sizeof(int) * 11 * (size_t)cmax);
+    d.moves = (uint8_t*)m_moves.ensure((size_t)(cmax + 1) * 64);
+    d.trace = (int*)m_trace.ensure(sizeof(int) * 2 * (size_t)(cmax + 64));
+    int* dout = (int*)m_out.ensure(sizeof(int) * 2);
+    d.ncol_out = dout; d.err_out = dout + 1;
+    launch_msa(st, d);
+    int out[2];
+    HIPCHK(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (out[1] & 0xFF) throw ScError(SC_ERR_UNSUPPORTED, "MSA kernel capacity exceeded");
+    const int ncol = out[0], cur = out[1] >> 8;
+    std::vector<char> cols((size_t)ncol * n);
+    if (ncol > 0) HIPCHK(hipMemcpy(cols.data(), d.cols[cur], (size_t)ncol * n, hipMemcpyDeviceToHost));
+    rows.assign(n, std::string((size_t)ncol, '-'));
+    for (int c = 0; c < ncol; c++)
+        for (int k = 0; k < n; k++) rows[k][c] = cols[(size_t)c * n + k];
+    return ncol;
+}
+
+static inline double logprob_tab(const HStrain& s, int a, int b) {      // Strain.cpp:132-135
+    const double c = a < 6 ? s.comp[a] : 0.0;
+    return std::log(s.sub[a * KMAX + b]) - std::log(c);
+}
+static void recount(HStrain& s) {                                         // Strain.cpp:115-124
+    s.Z = 0;
+    for (int i = 0; i < 6; i++) {
+        s.comp[i] = 0;
+        for (int j = 0; j < 6; j++) s.comp[i] += s.sub[i * KMAX + j];
+        s.Z += s.comp[i];
+    }
+}
+static uint64_t hash_extend(uint64_t h, const std::string& lab) {
+    for (unsigned char c : lab) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+static void fmt_g17(std::string& out, double v) {
+    char b[64];
+    snprintf(b, sizeof b, "%.17g", v);
+    out += b;
+}
+
+void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
+    const int n_reads = (int)job.reads.size();
+    const sc_params& pa = job.params;
+    const double e = (double)pa.error_rate, tau = (double)pa.tau, diff = (double)pa.diff_rate;
+    const int K = f.K;
+
+    // ---- pseudo level holding every read once, for read_assign (NonparametricClustering.cpp:776-836)
+    const int final_e0 = (int)f.ent_rid.size();
+    long total_copies = 0;
+    {
+        int qo = 0;
+        for (int i = 0; i < n_reads; i++) {
+            f.ent_rid.push_back(i); f.ent_cn.push_back(job.reads[i].cn); f.ent_lab_off.push_back(0);
+            f.ent_lab_len.push_back(0); f.ent_first.push_back(1); f.ent_node.push_back(-1);
+            qo += job.reads[i].cn;
+        }
+        total_copies = qo;
+    }
+    // prefix of copy numbers inside each level
+    std::vector<int> ent_qoff(f.ent_rid.size(), 0);
+    int max_level_entries = n_reads, max_level_q = 0;
+    for (int l = 0; l < f.n_levels; l++) {
+        int qo = 0;
+        for (int x = f.level_ent_ptr[l]; x < f.level_ent_ptr[l + 1]; x++) { ent_qoff[x] = qo; qo += f.ent_cn[x]; }
+        max_level_entries = std::max(max_level_entries, f.level_ent_ptr[l + 1] - f.level_ent_ptr[l]);
+        max_level_q = std::max(max_level_q, qo);
+    }
+    { int qo = 0; for (int i = 0; i < n_reads; i++) { ent_qoff[final_e0 + i] = qo; qo += job.reads[i].cn; } }
+    const long qcap = std::max<long>(std::max<long>(max_level_q, total_copies), 1);
+
+    // ---- upload the static arrays
+    JobDev jd{};
+    jd.ent_rid = upload(b_ent_rid, f.ent_rid, st);
+    jd.ent_cn = upload(b_ent_cn, f.ent_cn, st);
+    jd.ent_lab_off = upload(b_ent_lab_off, f.ent_lab_off, st);
+    jd.ent_lab_len = upload(b_ent_lab_len, f.ent_lab_len, st);
+    jd.ent_first = upload(b_ent_first, f.ent_first, st);
+    jd.ent_qoff = upload(b_ent_qoff, ent_qoff, st);
+    jd.labels = upload(b_labels, f.labels, st);
+    jd.mate_ptr = upload(b_mate_ptr, job.mate_off, st);
+    jd.mate_idx = upload(b_mate_idx, job.mate_idx, st);
+    jd.n_reads = n_reads; jd.K = K; jd.code_N = f.code_N;
+    jd.ll_stride = ((long)n_reads + 3) & ~3L;
+    jd.ll = (double*)b_ll.ensure(sizeof(double) * (size_t)jd.ll_stride * MAXS);
+    jd.has = (uint8_t*)b_has.ensure((size_t)n_reads + 8);
+    HIPCHK(hipMemsetAsync(jd.has, 0, (size_t)n_reads + 8, st));
+    jd.U = ctx->dU;
+    jd.isnew = (uint8_t*)b_isnew.ensure((size_t)max_level_entries + 8);
+    jd.qcap = qcap;
+    jd.tabA = (double*)b_tabA.ensure(sizeof(double) * (size_t)qcap * MAXS);
+    jd.tabL = (double*)b_tabL.ensure(sizeof(double) * (size_t)std::min<long>(qcap, MAX_DRAWS) * 128);
+    jd.qflag = (uint8_t*)b_qflag.ensure((size_t)qcap + 8);
+    jd.qcode = (uint8_t*)b_qcode.ensure((size_t)qcap + 8);
+    jd.qent = (int*)b_qent.ensure(sizeof(int) * (size_t)qcap);
+    jd.quid = (int*)b_quid.ensure(sizeof(int) * (size_t)qcap);
+
+    // ---- a16: every edge support on the device
+    {
+        std::vector<int> esrc(f.out_node.size());
+        for (int a = 0; a < f.n_nodes; a++) for (int x = f.out_ptr[a]; x < f.out_ptr[a + 1]; x++) esrc[x] = a;
+        int* d_out_ptr = upload(b_out_ptr, f.out_ptr, st);
+        int* d_out_node = upload(b_out_node, f.out_node, st);
+        int* d_pool_ptr = upload(b_pool_ptr, f.pool_ptr, st);
+        int* d_pool_rid = upload(b_pool_rid, f.pool_rid, st);
+        int* d_pool_cn = upload(b_pool_cn, f.pool_cn, st);
+        uint8_t* d_isend = upload(b_isend, f.node_is_end, st);
+        int* d_esrc = upload(b_esrc, esrc, st);
+        int* d_sup = (int*)b_support.ensure(sizeof(int) * std::max<size_t>(esrc.size(), 1));
+        launch_edge_support(st, d_out_ptr, d_out_node, d_pool_ptr, d_pool_rid, d_pool_cn, d_isend, d_esrc, (int)esrc.size(),
+                            f.pools_sorted ? 1 : 0, d_sup);
+        if (!esrc.empty())
+            HIPCHK(hipMemcpyAsync(f.out_support.data(), d_sup, sizeof(int) * esrc.size(), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        job.edge_support = f.out_support;
+    }
+
+    // ---- level walk
+    std::vector<HStrain> level_strains, sub_strains;
+    std::vector<PathRec> arena;
+    std::vector<int> free_slots;
+    for (int i = MAXS - 1; i >= 0; i--) free_slots.push_back(i);
+    std::vector<HStrain> final_strains;
+    std::string& tr = job.trace;
+    const bool want_trace = pa.want_trace != 0;
+
+    auto strain_seq = [&](const HStrain& s) {
+        std::vector<int> rev;
+        for (int t = s.tail; t >= 0; t = arena[t].parent) rev.push_back(arena[t].node);
+        std::string q;
+        for (auto it = rev.rbegin(); it != rev.rend(); ++it) q += f.node_label_str[*it];
+        return q;
+    };
+    auto trace_dump = [&](const char* when, int level, const std::vector<HStrain>& sv) {
+        if (!want_trace || sv.empty()) return;
+        tr += "------------------------------\n"; tr += when; tr += "\nlevel: "; tr += std::to_string(level); tr += "\n";
+        for (const auto& s : sv) { tr += strain_seq(s); tr += "\t"; fmt_g17(tr, s.abundance); tr += "\n"; }
+    };
+    auto sort_strains = [&](std::vector<HStrain>& sv) {                  // std::sort, abundance descending
+        std::vector<int> perm(sv.size());
+        for (size_t i = 0; i < sv.size(); i++) perm[i] = (int)i;
+        std_sort_perm(perm, [&](int a, int b) { return sv[a].abundance > sv[b].abundance; });
+        std::vector<HStrain> t;
+        t.reserve(sv.size());
+        for (int i : perm) t.push_back(sv[i]);
+        sv.swap(t);
+    };
+    auto seq_identity = [](const std::string& a, const std::string& b) {  // NonparametricClustering.cpp:584-612
+        int iden = 0, len = 0;
+        for (size_t i = 0; i < a.size(); ++i) {
+            const char x = a[i], y = i < b.size() ? b[i] : 0;
+            if (x == '-' && y == '-') continue;
+            else if (x == '=' && y == '=') continue;
+            else if (x == '=' && y == '-') continue;
+            else if (x == '-' && y == '=') continue;
+            else if (x == '^' && y == '^') continue;
+            else if (x == y) iden += 1;
+            len += 1;
+        }
+        return (iden + 0.0) / len;
+    };
+
+    {   // level_strains.push_back(Strain(100,e)), NonparametricClustering.cpp:281; Strain.cpp:41-71
+        HStrain s{};
+        for (int i = 0; i < KK; i++) s.sub[i] = 0;
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) s.sub[i * KMAX + j] = (i == j) ? 100 * (1 - e) : 100 * e;
+        recount(s);
+        s.abundance = 0; s.slot = free_slots.back(); free_slots.pop_back();
+        s.tail = -1; s.node = -1; s.hash = 1469598103934665603ull; s.seqlen = 0;
+        level_strains.push_back(s);
+    }
+    bool branching = false;
+    std::vector<std::pair<int, int>> pending_copies;     // (src slot, dst slot) for the next launch
+    double sampler_ms = 0;
+    long sampler_launches = 0, level_launches = 0, draws = 0, exact = 0;
+
+    auto run_level = [&](int mode, int e0, int e1, int Q, int n_sweeps, bool do_update, const std::vector<HStrain>& sv,
+                         bool has_dups, bool any_multi) {
+        LevelParams& P = *Ph;
+        const int S = (int)sv.size();
+        P.mode = mode; P.S = S; P.e0 = e0; P.e1 = e1; P.has_dups = has_dups; P.any_multi = any_multi; P.Q = Q;
+        P.n_sweeps = n_sweeps;
+        P.n_copy = (int)pending_copies.size();
+        for (int c = 0; c < P.n_copy; c++) { P.copy_src[c] = pending_copies[c].first; P.copy_dst[c] = pending_copies[c].second; }
+        pending_copies.clear();
+        double za = 0;
+        for (int s = 0; s < S; s++) za += sv[s].abundance;                 // normalize(), :10-15
+        for (int s = 0; s < S; s++) {
+            P.slot[s] = sv[s].slot;
+            P.lab_off[s] = sv[s].node >= 0 ? f.node_lab_off[sv[s].node] : 0;
+            P.lab_len[s] = sv[s].node >= 0 ? f.node_lab_len[sv[s].node] : 0;
+            P.a0[s] = sv[s].abundance;
+            P.logpri[s] = std::log(sv[s].abundance / za);
+            double* lp = P.lpt + (size_t)s * KK;
+            for (int a = 0; a < KMAX; a++)
+                for (int b = 0; b < KMAX; b++) lp[a * KMAX + b] = (a < K && b < K) ? logprob_tab(sv[s], a, b) : 0.0;
+        }
+        const size_t bytes = offsetof(LevelParams, lpt) + sizeof(double) * (size_t)S * KK;
+        HIPCHK(hipMemcpyAsync(Pd, Ph, bytes, hipMemcpyHostToDevice, st));
+        const bool timed = (mode == MODE_SAMPLE);
+        if (timed) HIPCHK(hipEventRecord(ev0, st));
+        launch_level(st, jd, Pd, Rd, do_update ? 1 : 0);
+        if (timed) HIPCHK(hipEventRecord(ev1, st));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        level_launches++;
+        if (timed) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+            sampler_ms += ms; sampler_launches++;
+            draws += (long)Rh->n_draws; exact += (long)Rh->n_exact;
+        }
+    };
+
+    for (int level = 0; level < f.n_levels; level++) {
+        const int n0 = f.level_node_ptr[level], n1 = f.level_node_ptr[level + 1];
+        for (int x = n0; x < n1; x++) {
+            trace_dump("before clustering", level, level_strains);
+            const int u = f.level_nodes[x];
+            if (u == 0) {
+                if (level_strains.empty()) throw ScError(SC_ERR_INTERNAL, "no strain at the root");
+                HStrain& s = level_strains[0];
+                arena.push_back({0, s.tail});
+                s.tail = (int)arena.size() - 1; s.node = 0;
+                s.hash = hash_extend(s.hash, f.node_label_str[0]); s.seqlen += (int)f.node_label_str[0].size();
+                s.abundance = 1;
+            } else if (f.node_is_end[u]) {
+                // read_reassign (only its sort has an effect, :672-702), merge_strains (:645-670)
+                if (level_strains.empty()) throw ScError(SC_ERR_INTERNAL, "every candidate strain was pruned");
+                sort_strains(level_strains);
+                sort_strains(level_strains);
+                std::vector<std::string> seqs;
+                for (auto& s : level_strains) seqs.push_back(strain_seq(s));
+                std::vector<int> merged{0};
+                for (int i = 1; i < (int)level_strains.size(); i++) {
+                    size_t j;
+                    for (j = 0; j < merged.size(); j++)
+                        if (seq_identity(seqs[i], seqs[merged[j]]) > 1 - diff) {
+                            level_strains[merged[j]].abundance += level_strains[i].abundance;
+                            break;
+                        }
+                    if (j == merged.size()) merged.push_back(i);
+                }
+                std::vector<HStrain> kept;
+                std::vector<char> keep(level_strains.size(), 0);
+                for (int j : merged) { kept.push_back(level_strains[j]); keep[j] = 1; }
+                for (size_t i = 0; i < level_strains.size(); i++) if (!keep[i]) free_slots.push_back(level_strains[i].slot);
+                level_strains.swap(kept);
+                final_strains = level_strains;
+            }
+        }
+        const int e0 = f.level_ent_ptr[level], e1 = f.level_ent_ptr[level + 1];
+        const int Rn = e1 - e0;
+        if (Rn > 0 && !level_strains.empty()) {
+            const int S = (int)level_strains.size();
+            if (S > MAXS) throw ScError(SC_ERR_CAPACITY, "more than 128 candidate strains at one level");
+            bool has_dups = false, any_multi = false;
+            for (int x = e0; x < e1; x++) { if (!f.ent_first[x]) has_dups = true; if (f.ent_lab_len[x] != 1) any_multi = true; }
+            for (auto& s : level_strains) if (f.node_lab_len[s.node] != 1) any_multi = true;
+            const int Q = f.level_read_count[level];
+            if (branching) {
+                // np_bayes_clustering, :128-244 (+ pruning :404-454)
+                const int n = std::min(pa.sweeps_cap, pa.draw_budget / Q);
+                std::vector<uint64_t> hs(S); std::vector<int> ln(S), last(S);
+                for (int s = 0; s < S; s++) { hs[s] = level_strains[s].hash; ln[s] = level_strains[s].seqlen; }
+                for (int s = 0; s < S; s++) {
+                    last[s] = s;
+                    for (int t = S - 1; t > s; t--) if (hs[t] == hs[s] && ln[t] == ln[s]) { last[s] = t; break; }
+                }
+                std::vector<double> prior(S), post(S), a(S);
+                for (int s = 0; s < S; s++) prior[s] = level_strains[last[s]].abundance;
+                run_level(MODE_SAMPLE, e0, e1, Q, n, true, level_strains, has_dups, any_multi);
+                std::vector<std::vector<double>> cnt(S, std::vector<double>(KMAX, 0.0));
+                if (S == 1 || n <= 0) {
+                    // a single weight consumes no random numbers (libstdc++ discrete_distribution)
+                    a[0] = level_strains[0].abundance;
+                    for (int s = 1; s < S; s++) a[s] = level_strains[s].abundance;
+                    if (n > 0) {
+                        const long tot = (long)n * Q;
+                        for (long t = 0; t < tot; t++) a[0] += 1;
+                        for (int x = e0; x < e1; x++)
+                            if (f.ent_lab_len[x] == 1) cnt[0][f.labels[f.ent_lab_off[x]]] += (double)n * f.ent_cn[x];
+                    }
+                } else {
+                    for (int s = 0; s < S; s++) {
+                        a[s] = Rh->abund[s];
+                        for (int b = 0; b < KMAX; b++) cnt[s][b] = (double)Rh->cnt[s * KMAX + b];
+                    }
+                }
+                double z = 0;
+                for (int s = 0; s < S; s++) z += a[s];
+                for (int s = 0; s < S; s++) a[s] /= z;
+                for (int s = 0; s < S; s++) a[s] *= Q;
+                for (int s = 0; s < S; s++) {
+                    HStrain& st_ = level_strains[s];
+                    st_.abundance += a[s];                                   // update_model, Strain.cpp:106-125
+                    if (f.node_lab_len[st_.node] == 1) {
+                        const int la = f.labels[f.node_lab_off[st_.node]];
+                        if (la < KMAX)
+                            for (int b = 0; b < K; b++) if (cnt[s][b] > 0) st_.sub[la * KMAX + b] += cnt[s][b] / n;
+                    }
+                    recount(st_);
+                }
+                for (int s = 0; s < S; s++) post[s] = level_strains[last[s]].abundance;
+                double A_delta_max = 0;
+                for (int s = 0; s < S; s++) { double d = post[s] - prior[s]; if (A_delta_max < d) A_delta_max = d; }
+                double Z = 0;
+                for (int s = 0; s < S; s++) Z += a[s];
+                const double Zt = Z * tau;
+                std::vector<HStrain> kept;
+                for (int s = 0; s < S; s++) {
+                    const double d = post[s] - prior[s];
+                    if (a[s] < Zt || d < 0.01 * A_delta_max) free_slots.push_back(level_strains[s].slot);
+                    else kept.push_back(level_strains[s]);
+                }
+                level_strains.swap(kept);
+            } else {
+                // hard_clustering, :17-125
+                run_level(MODE_HARD, e0, e1, Q, 0, true, level_strains, has_dups, any_multi);
+                for (int s = 0; s < S; s++) {
+                    HStrain& st_ = level_strains[s];
+                    st_.abundance += Rh->abund[s];
+                    for (int a = 0; a < K; a++)
+                        for (int b = 0; b < K; b++) st_.sub[a * KMAX + b] += Rh->subst[s * KK + a * KMAX + b];
+                    recount(st_);
+                }
+            }
+        }
+        trace_dump("after clustering", level, level_strains);
+
+        // ---- candidate extension, :473-551
+        branching = false;
+        struct Cand { int parent; int node; double abundance; };
+        std::vector<Cand> cands;
+        for (int si = 0; si < (int)level_strains.size(); si++) {
+            const HStrain& s = level_strains[si];
+            const int v = s.node;
+            const int ob = f.out_ptr[v], oe = f.out_ptr[v + 1];
+            double oz = 0, moc = 0;
+            for (int x = ob; x < oe; x++) { const double oc0 = f.out_support[x]; oz += oc0; if (moc < oc0) moc = oc0; }
+            int dd = 0;
+            for (int x = ob; x < oe; x++) {
+                const int o = f.out_node[x];
+                const double oc = f.out_support[x];
+                if (!f.node_is_end[o] && oz > 0) {
+                    if (oc <= 1. && oc < moc) { dd += 1; continue; }
+                    double ab;
+                    if (oc > 0) ab = s.abundance * oc / oz;
+                    else ab = oz * std::min(0.01, (double)tau);
+                    cands.push_back({si, o, ab});
+                } else {
+                    cands.push_back({si, o, s.abundance});
+                }
+            }
+            if (oe - ob > 1 + dd) branching = true;
+        }
+        if ((int)cands.size() > pa.max_candidates) {                          // :532-551, Qx :246-254
+            std::vector<double> ssa;
+            for (auto& c : cands) ssa.push_back(c.abundance);
+            std::sort(ssa.begin(), ssa.end(), [](double x, double y) { return x > y; });
+            const double Zt0 = (pa.max_candidates >= (int)ssa.size()) ? ssa.back() : ssa[pa.max_candidates];
+            std::vector<Cand> kept;
+            for (auto& c : cands) if (!(c.abundance < Zt0)) kept.push_back(c);
+            cands.swap(kept);
+        }
+        if ((int)cands.size() > MAXS) throw ScError(SC_ERR_CAPACITY, "more than 128 candidate strains at one level");
+        // materialise: the first surviving child of a parent inherits its row, the others copy it
+        std::vector<int> first_child(level_strains.size(), -1);
+        for (int c = 0; c < (int)cands.size(); c++) if (first_child[cands[c].parent] < 0) first_child[cands[c].parent] = c;
+        for (size_t p = 0; p < level_strains.size(); p++) if (first_child[p] < 0) free_slots.push_back(level_strains[p].slot);
+        sub_strains.clear();
+        for (int c = 0; c < (int)cands.size(); c++) {
+            const HStrain& par = level_strains[cands[c].parent];
+            HStrain ns = par;
+            if (first_child[cands[c].parent] == c) ns.slot = par.slot;
+            else {
+                if (free_slots.empty()) throw ScError(SC_ERR_CAPACITY, "out of read_loglik rows");
+                ns.slot = free_slots.back(); free_slots.pop_back();
+                pending_copies.push_back({par.slot, ns.slot});
+            }
+            arena.push_back({cands[c].node, par.tail});
+            ns.tail = (int)arena.size() - 1; ns.node = cands[c].node;
+            ns.hash = hash_extend(par.hash, f.node_label_str[cands[c].node]);
+            ns.seqlen = par.seqlen + (int)f.node_label_str[cands[c].node].size();
+            ns.abundance = cands[c].abundance;
+            sub_strains.push_back(ns);
+        }
+        level_strains.swap(sub_strains);
+        sub_strains.clear();
+    }
+
+    // ---- read_assign, :776-836, then the final sort, StrainCall.cpp:1027
+    std::vector<HStrain>& fs = final_strains;
+    const int S = (int)fs.size();
+    if (S > 0) {
+        const int Q = (int)total_copies;
+        const int n = std::min(pa.sweeps_cap, pa.draw_budget / std::max(Q, 1));
+        std::vector<double> a(S);
+        if (S == 1 || n <= 0) {
+            for (int s = 0; s < S; s++) a[s] = fs[s].abundance;
+            if (n > 0) { const long tot = (long)n * Q; for (long t = 0; t < tot; t++) a[0] += 1; }
+        } else {
+            pending_copies.clear();
+            run_level(MODE_SAMPLE, final_e0, final_e0 + n_reads, Q, n, false, fs, false, true);
+            for (int s = 0; s < S; s++) a[s] = Rh->abund[s];
+        }
+        double z = 0;
+        for (int s = 0; s < S; s++) z += a[s];
+        for (int s = 0; s < S; s++) fs[s].abundance = a[s] / z;
+        sort_strains(fs);
+        for (auto& s : fs) {
+            std::string q;
+            std::vector<int> rev;
+            for (int t = s.tail; t >= 0; t = arena[t].parent) rev.push_back(arena[t].node);
+            for (auto it = rev.rbegin(); it != rev.rend(); ++it) {
+                const std::string& pl = f.node_label_str[*it];                 // Strain::plain_seq, Strain.cpp:211-223
+                if (pl != "^" && pl != "$" && pl != "-" && pl != "=") q += pl;
+            }
+            job.seqs.push_back(q);
+            job.abund.push_back(s.abundance);
+        }
+    }
+    job.stats.sampler_kernel_ms = sampler_ms;
+    job.stats.sampler_launches = sampler_launches;
+    job.stats.level_launches = level_launches;
+    job.stats.draws = draws;
+    job.stats.exact_draws = exact;
+}
+
+void Worker::process(Job& job) {
+    const double t0 = now_ms();
+    MsaFn msa = [this](const std::vector<std::string>& seqs, std::vector<std::string>& rows) { return msa_device(seqs, rows); };
+    PoGraph g(job.ref, job.reads, msa);
+    job.stats.msa_calls = g.msa_calls;
+    job.graph_dump = g.dump();
+    FlatGraph f;
+    flatten(g, (int)job.reads.size(), f);
+    job.stats.n_nodes = f.n_nodes; job.stats.n_levels = f.n_levels; job.stats.n_unique_reads = (int)job.reads.size();
+    long copies = 0;
+    for (auto& r : job.reads) copies += r.cn;
+    job.stats.n_read_copies = copies;
+    const double t1 = now_ms();
+    job.stats.graph_ms = t1 - t0;
+    if (!job.params.graph_only) {
+        if (!f.unsupported.empty()) throw ScError(SC_ERR_UNSUPPORTED, f.unsupported);
+        cluster(job, g, f);
+    }
+    job.stats.cluster_ms = now_ms() - t1;
+}
+
+void Worker::run() {
+    try { init(); } catch (const std::exception& ex) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->last_error = ex.what();
+    }
+    for (;;) {
+        std::shared_ptr<Job> job;
+        {
+            std::unique_lock<std::mutex> lk(ctx->mu);
+            ctx->cv_job.wait(lk, [&] { return ctx->stop || !ctx->queue.empty(); });
+            if (ctx->stop && ctx->queue.empty()) break;
+            job = ctx->queue.front(); ctx->queue.pop_front();
+        }
+        try {
+            if (!st) throw HipError("worker stream was not created");
+            process(*job);
+            job->rc = SC_OK;
+        } catch (const ScError& ex) { job->rc = ex.code; job->err = ex.what(); }
+        catch (const HipError& ex) { job->rc = SC_ERR_HIP; job->err = ex.what(); }
+        catch (const std::exception& ex) { job->rc = SC_ERR_INTERNAL; job->err = ex.what(); }
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            job->status = 1;
+            if (job->rc != SC_OK) ctx->last_error = job->err;
+        }
+        ctx->cv_done.notify_all();
+    }
+}
+
+}  // namespace sc
+
+using namespace sc;
+struct sc_ctx { Ctx c; };
+
+extern "C" {
+
+int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
+    if (!out) return SC_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SC_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SC_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SC_ERR_NO_DEVICE;   // kernels are built for gfx950 only
+    if (hipSetDevice(device) != hipSuccess) return SC_ERR_HIP;
+    if (init_kernels() != 0) return SC_ERR_HIP;
+    sc_ctx* h = new sc_ctx();
+    Ctx* ctx = &h->c;
+    ctx->device = device;
+    std::vector<double> u = uniform_stream(1234u, MAX_DRAWS + 64);
+    if (hipMalloc((void**)&ctx->dU, sizeof(double) * u.size()) != hipSuccess ||
+        hipMemcpy(ctx->dU, u.data(), sizeof(double) * u.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        delete h;
+        return SC_ERR_HIP;
+    }
+    if (stream_count < 1) stream_count = 1;
+    if (stream_count > 64) stream_count = 64;
+    for (int i = 0; i < stream_count; i++) {
+        auto w = std::make_unique<Worker>();
+        w->ctx = ctx;
+        ctx->workers.push_back(std::move(w));
+    }
+    for (auto& w : ctx->workers) w->th = std::thread([p = w.get()] { p->run(); });
+    *out = h;
+    return SC_OK;
+}
+
+void sc_ctx_destroy(sc_ctx* h) {
+    if (!h) return;
+    Ctx* ctx = &h->c;
+    { std::lock_guard<std::mutex> lk(ctx->mu); ctx->stop = true; }
+    ctx->cv_job.notify_all();
+    for (auto& w : ctx->workers) if (w->th.joinable()) w->th.join();
+    (void)hipSetDevice(ctx->device);
+    for (auto& w : ctx->workers) {
+        if (w->Ph) (void)hipHostFree(w->Ph);
+        if (w->Pd) (void)hipFree(w->Pd);
+        if (w->Rh) (void)hipHostFree(w->Rh);
+        if (w->ev0) (void)hipEventDestroy(w->ev0);
+        if (w->ev1) (void)hipEventDestroy(w->ev1);
+        if (w->st) (void)hipStreamDestroy(w->st);
+    }
+    ctx->workers.clear();
+    if (ctx->dU) (void)hipFree(ctx->dU);
+    delete h;
+}
+
+const char* sc_last_error(sc_ctx* h) {
+    if (!h) return "";
+    std::lock_guard<std::mutex> lk(h->c.mu);
+    static thread_local std::string copy;
+    copy = h->c.last_error;
+    return copy.c_str();
+}
+
+int sc_roi_submit(sc_ctx* h, const char* ref_bases, int ref_len, const int* read_pos, const char* cigar_text,
+                  const int* cigar_off, const char* seq_text, const int* seq_off, const int* read_copies,
+                  const int* mate_idx, const int* mate_off, int n_reads, const sc_params* params, int* handle_out) {
+    if (!h || !ref_bases || ref_len < 0 || n_reads < 0 || !params || !handle_out) return SC_ERR_ARG;
+    if (n_reads > 0 && (!read_pos || !cigar_text || !cigar_off || !seq_text || !seq_off || !read_copies || !mate_off)) return SC_ERR_ARG;
+    auto job = std::make_shared<Job>();
+    job->ref.assign(ref_bases, (size_t)ref_len);
+    job->reads.resize((size_t)n_reads);
+    for (int i = 0; i < n_reads; i++) {
+        if (read_pos[i] < 0 || read_pos[i] > ref_len) return SC_ERR_ARG;
+        job->reads[i].pos = read_pos[i];
+        job->reads[i].cigar.assign(cigar_text + cigar_off[i], (size_t)(cigar_off[i + 1] - cigar_off[i]));
+        job->reads[i].seq.assign(seq_text + seq_off[i], (size_t)(seq_off[i + 1] - seq_off[i]));
+        job->reads[i].cn = read_copies[i];
+    }
+    job->mate_off.assign(mate_off ? mate_off : nullptr, mate_off ? mate_off + n_reads + 1 : nullptr);
+    if (job->mate_off.empty()) job->mate_off.assign(1, 0);
+    const int nm = job->mate_off.back();
+    if (nm > 0 && !mate_idx) return SC_ERR_ARG;
+    job->mate_idx.assign(mate_idx, mate_idx + nm);
+    for (int v : job->mate_idx) if (v < -1 || v >= n_reads) return SC_ERR_ARG;
+    job->params = *params;
+    Ctx* ctx = &h->c;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        job->handle = ctx->next_handle++;
+        ctx->jobs[job->handle] = job;
+        ctx->queue.push_back(job);
+        *handle_out = job->handle;
+    }
+    ctx->cv_job.notify_one();
+    return SC_OK;
+}
+
+static std::shared_ptr<Job> find_job(sc_ctx* h, int handle) {
+    std::lock_guard<std::mutex> lk(h->c.mu);
+    auto it = h->c.jobs.find(handle);
+    return it == h->c.jobs.end() ? nullptr : it->second;
+}
+
+int sc_roi_wait(sc_ctx* h, int handle) {
+    if (!h) return SC_ERR_ARG;
+    auto job = find_job(h, handle);
+    if (!job) return SC_ERR_ARG;
+    std::unique_lock<std::mutex> lk(h->c.mu);
+    h->c.cv_done.wait(lk, [&] { return job->status == 1; });
+    if (job->rc != SC_OK) h->c.last_error = job->err;
+    return job->rc;
+}
+
+int sc_roi_result(sc_ctx* h, int handle, char* seq_buf, long seq_cap, int* seq_off, double* abundance, int max_strains,
+                  int* n_strains) {
+    if (!h || !n_strains) return SC_ERR_ARG;
+    auto job = find_job(h, handle);
+    if (!job || job->status != 1) return SC_ERR_ARG;
+    if (job->rc != SC_OK) return job->rc;
+    const int n = (int)job->seqs.size();
+    *n_strains = n;
+    long tot = 0;
+    for (auto& s : job->seqs) tot += (long)s.size();
+    if (n > max_strains || tot > seq_cap || !seq_buf || !seq_off || !abundance) return SC_ERR_CAPACITY;
+    long o = 0;
+    for (int i = 0; i < n; i++) {
+        seq_off[i] = (int)o;
+        std::memcpy(seq_buf + o, job->seqs[i].data(), job->seqs[i].size());
+        o += (long)job->seqs[i].size();
+        abundance[i] = job->abund[i];
+    }
+    seq_off[n] = (int)o;
+    return SC_OK;
+}
+
+static int copy_text(const std::string& s, char* buf, long cap, long* len_out) {
+    if (len_out) *len_out = (long)s.size();
+    if (!buf || cap < (long)s.size()) return SC_ERR_CAPACITY;
+    std::memcpy(buf, s.data(), s.size());
+    return SC_OK;
+}
+int sc_roi_graph_dump(sc_ctx* h, int handle, char* buf, long cap, long* len_out) {
+    if (!h) return SC_ERR_ARG;
+    auto job = find_job(h, handle);
+    if (!job || job->status != 1) return SC_ERR_ARG;
+    if (job->rc != SC_OK && job->graph_dump.empty()) return job->rc;
+    return copy_text(job->graph_dump, buf, cap, len_out);
+}
+int sc_roi_trace(sc_ctx* h, int handle, char* buf, long cap, long* len_out) {
+    if (!h) return SC_ERR_ARG;
+    auto job = find_job(h, handle);
+    if (!job || job->status != 1) return SC_ERR_ARG;
+    if (job->rc != SC_OK) return job->rc;
+    return copy_text(job->trace, buf, cap, len_out);
+}
+int sc_roi_stats(sc_ctx* h, int handle, sc_stats* out) {
+    if (!h || !out) return SC_ERR_ARG;
+    auto job = find_job(h, handle);
+    if (!job || job->status != 1) return SC_ERR_ARG;
+    *out = job->stats;
+    return SC_OK;
+}
+int sc_roi_edge_support(sc_ctx* h, int handle, int* support, int cap, int* n_edges) {
+    if (!h || !n_edges) return SC_ERR_ARG;
+    auto job = find_job(h, handle);
+    if (!job || job->status != 1) return SC_ERR_ARG;
+    if (job->rc != SC_OK) return job->rc;
+    *n_edges = (int)job->edge_support.size();
+    if (!support || cap < *n_edges) return SC_ERR_CAPACITY;
+    std::memcpy(support, job->edge_support.data(), sizeof(int) * job->edge_support.size());
+    return SC_OK;
+}
+int sc_roi_release(sc_ctx* h, int handle) {
+    if (!h) return SC_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->c.mu);
+    auto it = h->c.jobs.find(handle);
+    if (it == h->c.jobs.end() || it->second->status != 1) return SC_ERR_ARG;
+    h->c.jobs.erase(it);
+    return SC_OK;
+}
+
+int sc_msa_align(sc_ctx* h, const char* seq_text, const int* seq_off, int n, char* rows_out, long cap, int* ncol_out) {
+    if (!h || !seq_text || !seq_off || n < 1 || !ncol_out) return SC_ERR_ARG;
+    Ctx* ctx = &h->c;
+    // runs on a private worker object (own stream) so it can be called while regions are in flight
+    try {
+        HIPCHK(hipSetDevice(ctx->device));
+        Worker w;
+        w.ctx = ctx;
+        w.init();
+        std::vector<std::string> seqs((size_t)n), rows;
+        for (int i = 0; i < n; i++) seqs[i].assign(seq_text + seq_off[i], (size_t)(seq_off[i + 1] - seq_off[i]));
+        int ncol;
+        if (n == 1) { ncol = (int)seqs[0].size(); rows = seqs; }
+        else ncol = w.msa_device(seqs, rows);
+        *ncol_out = ncol;
+        int rc = SC_OK;
+        if (!rows_out || (long)n * (ncol + 1) > cap) rc = SC_ERR_CAPACITY;
+        else for (int i = 0; i < n; i++) { std::memcpy(rows_out + (long)i * (ncol + 1), rows[i].data(), (size_t)ncol); rows_out[(long)i * (ncol + 1) + ncol] = 0; }
+        (void)hipHostFree(w.Ph); (void)hipFree(w.Pd); (void)hipHostFree(w.Rh);
+        (void)hipEventDestroy(w.ev0); (void)hipEventDestroy(w.ev1); (void)hipStreamDestroy(w.st);
+        return rc;
+    } catch (const ScError& ex) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->last_error = ex.what(); return ex.code; }
+    catch (const std::exception& ex) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->last_error = ex.what(); return SC_ERR_HIP; }
+}
+
+}  // extern "C"

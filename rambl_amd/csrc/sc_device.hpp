@@ -1,0 +1,91 @@
+// Device-side data layout shared by the host driver (sc_cluster.cpp) and the
+// HIP kernels (sc_kernels.hip).  All pointers are device pointers unless the
+// field name ends in _h (host-mapped pinned memory written/read by kernels).
+#pragma once
+#include <cstdint>
+
+namespace sc {
+
+constexpr int MAXS = 128;        // candidate strains alive at one level (reference keeps <= ~81)
+constexpr int KMAX = 8;          // symbols: A C G T - = plus up to two others (e.g. N)
+constexpr int KK = KMAX * KMAX;
+constexpr int MAX_DRAWS = 40000; // NonparametricClustering.cpp:160 / :781 draw budget
+
+enum LevelMode { MODE_HARD = 0, MODE_SAMPLE = 1 };
+
+// Static per-ROI arrays (one set per job, resident in HBM for the whole walk).
+struct JobDev {
+    // level entries (NonparametricClustering.cpp:318-322 level_reads), level-major
+    const int* ent_rid;
+    const int* ent_cn;
+    const int* ent_lab_off;
+    const int* ent_lab_len;
+    const uint8_t* ent_first;
+    const int* ent_qoff;         // prefix sum of copy numbers inside the entry's level
+    const uint8_t* labels;       // symbol codes
+    // ReadPairs (PartialOrderGraph.hpp:88) as CSR: mate of copy k of read r = mate_idx[mate_ptr[r]+k]
+    const int* mate_ptr;
+    const int* mate_idx;
+    int n_reads;
+    int K;
+    int code_N;
+    // per-strain read log-likelihood rows (Strain::read_loglik), ll[slot*ll_stride + rid]
+    double* ll;
+    long ll_stride;
+    uint8_t* has;                // read present in read_loglik (identical for every strain)
+    const double* U;             // generate_canonical<double,53>(mt19937(1234)) stream, MAX_DRAWS values
+    // scratch
+    uint8_t* isnew;              // [max entries per level]
+    double* tabA;                // [MAXS][qcap]  LLq / P  (strain-major)
+    double* tabL;                // [qcap][SPAD]  sampler weights (draw-major)
+    uint8_t* qflag;              // [qcap] exact-path flag per draw slot
+    uint8_t* qcode;              // [qcap] read-label symbol code of a draw slot (0xFF: not a single symbol)
+    int* qent;                   // [qcap] entry index of a draw slot
+    int* quid;                   // [qcap] mate read id of a draw slot (-1 none)
+    long qcap;
+};
+
+// Per-level parameters: staged by the host in pinned memory and copied to the
+// device in front of the launch (only the first S rows of `lpt`, which is last).
+struct LevelParams {
+    int mode;
+    int S;                       // strains at this level
+    int e0, e1;                  // entry range
+    int has_dups;                // an rid occurs twice in this level
+    int any_multi;               // some label (strain node or entry) has more than one symbol
+    int Q;                       // read_size = sum of copy numbers
+    int n_sweeps;                // min(5000, 40000/Q)
+    int n_copy;                  // row copies to perform first
+    int copy_src[MAXS], copy_dst[MAXS];
+    int slot[MAXS];              // ll row of strain s
+    int lab_off[MAXS], lab_len[MAXS];   // node label of strain s (into labels)
+    double a0[MAXS];             // abundance before clustering
+    double logpri[MAXS];         // log(a_s / sum a) for the hard update
+    double lpt[MAXS * KK];       // log sub(a,b) - log comp(a) per strain
+};
+
+// Per-level results, written by the kernel into pinned memory.
+struct LevelResult {
+    double abund[MAXS];          // HARD: sum of responsibilities; SAMPLE: urn weights a[] after the sweeps
+    double subst[MAXS * KK];     // HARD: responsibility-weighted substitution counts
+    unsigned cnt[MAXS * KMAX];   // SAMPLE: draws per (strain, read symbol)
+    unsigned long long n_draws;
+    unsigned long long n_exact;  // draws resolved by the literal fp64 path
+    int error;
+};
+
+// Buffers of one progressive MSA call (k_msa).
+struct MsaDev {
+    const char* seqs;       // packed sequences
+    const int* seq_off;     // n + 1 offsets
+    int n;
+    int cmax;               // capacity in columns
+    char* cols[2];          // [cmax][n] column-major MSA, double buffered
+    int* counts;            // [cmax][11] character-class counts of the current columns
+    uint8_t* moves;         // [(cmax+1)][64] traceback moves: 0 diag, 1 insert(left), 2 delete(up)
+    int* trace;             // [2*cmax] traceback script
+    int* ncol_out;
+    int* err_out;
+};
+
+}  // namespace sc

@@ -1,0 +1,760 @@
+// Host graph builder + flattener.  See sc_graph.hpp.  Each function cites the
+// reference lines whose behaviour it reproduces
+// (/root/reference/StrainCall/PartialOrderGraph.cpp unless another file is named).
+#include "sc_graph.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+
+namespace sc {
+
+// ---------------------------------------------------------------------------
+// std::sort as libstdc++ permutes it (GCC <bits/stl_algo.h>: introsort with
+// median-of-three to first, unguarded partition, heap fallback, final insertion
+// sort with threshold 16).
+namespace {
+struct Sorter {
+    std::vector<int>& a;
+    const std::function<bool(int, int)>& less;
+    void linear_insert(int last) {
+        int val = a[last];
+        int next = last - 1;
+        while (less(val, a[next])) { a[last] = a[next]; last = next; --next; }
+        a[last] = val;
+    }
+    void insertion(int first, int last) {
+        if (first == last) return;
+        for (int i = first + 1; i != last; ++i) {
+            if (less(a[i], a[first])) {
+                int val = a[i];
+                std::move_backward(a.begin() + first, a.begin() + i, a.begin() + i + 1);
+                a[first] = val;
+            } else linear_insert(i);
+        }
+    }
+    void push_heap(int first, int hole, int top, int value) {
+        int parent = (hole - 1) / 2;
+        while (hole > top && less(a[first + parent], value)) {
+            a[first + hole] = a[first + parent];
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        a[first + hole] = value;
+    }
+    void adjust_heap(int first, int hole, int len, int value) {
+        const int top = hole;
+        int child = hole;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            if (less(a[first + child], a[first + child - 1])) child--;
+            a[first + hole] = a[first + child];
+            hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            a[first + hole] = a[first + child - 1];
+            hole = child - 1;
+        }
+        push_heap(first, hole, top, value);
+    }
+    void heap_sort(int first, int last) {
+        int len = last - first;
+        if (len >= 2) {
+            int parent = (len - 2) / 2;
+            for (;;) {
+                int value = a[first + parent];
+                adjust_heap(first, parent, len, value);
+                if (parent == 0) break;
+                parent--;
+            }
+        }
+        while (last - first > 1) {
+            --last;
+            int value = a[last];
+            a[last] = a[first];
+            adjust_heap(first, 0, last - first, value);
+        }
+    }
+    void median_to_first(int result, int x, int y, int z) {
+        if (less(a[x], a[y])) {
+            if (less(a[y], a[z])) std::swap(a[result], a[y]);
+            else if (less(a[x], a[z])) std::swap(a[result], a[z]);
+            else std::swap(a[result], a[x]);
+        } else if (less(a[x], a[z])) std::swap(a[result], a[x]);
+        else if (less(a[y], a[z])) std::swap(a[result], a[z]);
+        else std::swap(a[result], a[y]);
+    }
+    int partition(int first, int last, int pivot) {
+        for (;;) {
+            while (less(a[first], a[pivot])) ++first;
+            --last;
+            while (less(a[pivot], a[last])) --last;
+            if (!(first < last)) return first;
+            std::swap(a[first], a[last]);
+            ++first;
+        }
+    }
+    void introsort(int first, int last, int depth) {
+        while (last - first > 16) {
+            if (depth == 0) { heap_sort(first, last); return; }
+            --depth;
+            int mid = first + (last - first) / 2;
+            median_to_first(first, first + 1, mid, last - 1);
+            int cut = partition(first + 1, last, first);
+            introsort(cut, last, depth);
+            last = cut;
+        }
+    }
+};
+}  // namespace
+
+void std_sort_perm(std::vector<int>& idx, const std::function<bool(int, int)>& less) {
+    int n = (int)idx.size();
+    if (n == 0) return;
+    Sorter s{idx, less};
+    int lg = 0;
+    for (unsigned t = (unsigned)n; t > 1; t >>= 1) lg++;
+    s.introsort(0, n, lg * 2);
+    if (n > 16) {
+        s.insertion(0, 16);
+        for (int i = 16; i != n; ++i) s.linear_insert(i);
+    } else s.insertion(0, n);
+}
+
+// ---------------------------------------------------------------------------
+struct Cig { char op; int len; };
+static void parse_cigar(const std::string& c, std::vector<Cig>& out) {   // cpp:13-59
+    int v = 0;
+    for (char ch : c) {
+        switch (ch) {
+            case 'M': case 'I': case 'D': case 'N': case 'S': case 'H': case 'P':
+                out.push_back({ch, v}); v = 0; break;
+            case '=': case 'X':
+                out.push_back({'M', v}); v = 0; break;
+            default:
+                if (ch >= '0' && ch <= '9') v = v * 10 + (ch - '0');
+        }
+    }
+}
+
+int PoGraph::new_node(int st, const std::string& lab) {
+    nodes.emplace_back();
+    GNode& w = nodes.back();
+    w.st = st; w.lab = lab;
+    ++n_alive;
+    return (int)nodes.size() - 1;
+}
+void PoGraph::add_edge(int u, int w) { nodes[u].out.push_back(w); nodes[w].in.push_back(u); }
+void PoGraph::add_edge_gap(int u, const std::vector<int>& gap) {
+    int a = u;
+    for (int w : gap) { add_edge(a, w); a = w; }
+}
+void PoGraph::add_edge_gap_to(int u, int v, const std::vector<int>& gap) {
+    add_edge_gap(u, gap);
+    add_edge(gap.back(), v);
+}
+static inline void erase_first(std::vector<int>& v, int x) {
+    auto it = std::find(v.begin(), v.end(), x);
+    if (it != v.end()) v.erase(it);
+}
+void PoGraph::del_edge(int u, int v) { erase_first(nodes[u].out, v); erase_first(nodes[v].in, u); }
+bool PoGraph::linking(int u, int v) const {
+    const auto& o = nodes[u].out;
+    return std::find(o.begin(), o.end(), v) != o.end();
+}
+// cpp:406-444; the O(N) erase + renumbering is replaced by a tombstone, ids are
+// assigned once at the end (finalize_ids) -- the relative order is the same.
+void PoGraph::delete_node(int w, bool bridging) {
+    // note: in/out of w are not modified while we iterate them
+    for (int p : nodes[w].in) {
+        for (int c : nodes[w].out) {
+            if (bridging && !linking(p, c)) add_edge(p, c);
+            erase_first(nodes[c].in, w);
+        }
+        erase_first(nodes[p].out, w);
+    }
+    nodes[w].alive = false;
+    --n_alive;
+}
+
+int PoGraph::reads_cover(int u, int v) const {
+    const GNode &a = nodes[u], &b = nodes[v];
+    int n = 0;
+    if (u == 0) {
+        for (const auto& e : b.pool) n += e.cn;
+    } else if (b.lab == "$") {
+        for (const auto& e : a.pool) n += e.cn;
+    } else {
+        // sum over pairs with equal rid of v's copy number; pools are rid-sorted in
+        // practice, fall back to the quadratic form otherwise
+        bool sorted = true;
+        for (size_t i = 1; i < a.pool.size() && sorted; i++) sorted = a.pool[i - 1].rid <= a.pool[i].rid;
+        for (size_t i = 1; i < b.pool.size() && sorted; i++) sorted = b.pool[i - 1].rid <= b.pool[i].rid;
+        if (sorted) {
+            size_t i = 0, j = 0;
+            while (i < a.pool.size() && j < b.pool.size()) {
+                if (a.pool[i].rid < b.pool[j].rid) i++;
+                else if (a.pool[i].rid > b.pool[j].rid) j++;
+                else {
+                    int rid = a.pool[i].rid, mu = 0, sv = 0;
+                    while (i < a.pool.size() && a.pool[i].rid == rid) { mu++; i++; }
+                    while (j < b.pool.size() && b.pool[j].rid == rid) { sv += b.pool[j].cn; j++; }
+                    n += mu * sv;
+                }
+            }
+        } else {
+            for (const auto& x : a.pool) for (const auto& y : b.pool) if (x.rid == y.rid) n += y.cn;
+        }
+    }
+    return n;
+}
+
+// cpp:355-393
+void PoGraph::find_insert_from(int u, std::vector<GapEx>& out) {
+    std::vector<int> g, st;
+    st.push_back(u);
+    while (!st.empty()) {
+        int v = st.back(); st.pop_back();
+        if (v == u) {
+            for (int o : nodes[v].out) if (nodes[o].st == ST_INS) st.push_back(o);
+        } else if (nodes[v].st == ST_MAT || nodes[v].st == ST_MIS) {
+            out.push_back({u, v, g});
+            g.clear();
+        } else {
+            g.push_back(v);
+            for (int o : nodes[v].out) st.push_back(o);
+        }
+    }
+}
+
+// cpp:780-829.  Sets of (rid, copies).
+void PoGraph::find_common_read_pool(int a, int b, std::vector<std::pair<int, int>>& c) {
+    auto build = [&](int x, const std::vector<int>& adj) {
+        std::vector<std::pair<int, int>> s;
+        s.reserve(nodes[x].pool.size());
+        for (const auto& e : nodes[x].pool) s.emplace_back(e.rid, e.cn);
+        std::sort(s.begin(), s.end());
+        s.erase(std::unique(s.begin(), s.end()), s.end());
+        std::vector<std::pair<int, int>> rm;
+        for (int o : adj)
+            if (nodes[o].st == ST_INS || nodes[o].st == ST_DEL)
+                for (const auto& e : nodes[o].pool) rm.emplace_back(e.rid, e.cn);
+        if (!rm.empty()) {
+            std::sort(rm.begin(), rm.end());
+            std::vector<std::pair<int, int>> kept;
+            kept.reserve(s.size());
+            std::set_difference(s.begin(), s.end(), rm.begin(), rm.end(), std::back_inserter(kept));
+            s.swap(kept);
+        }
+        return s;
+    };
+    auto ar = build(a, nodes[a].out);
+    auto br = build(b, nodes[b].in);
+    c.clear();
+    std::set_intersection(ar.begin(), ar.end(), br.begin(), br.end(), std::back_inserter(c));
+}
+
+void PoGraph::add_dash_chain(int a, int b, int l, const std::vector<std::pair<int, int>>& crp) {
+    std::vector<int> gap;
+    for (int t = 0; t < l; ++t) {
+        int w = new_node(ST_INS, "-");
+        auto& pool = nodes[w].pool;
+        pool.reserve(crp.size());
+        for (const auto& rc : crp) pool.push_back({rc.first, rc.second, "-"});
+        gap.push_back(w);
+    }
+    add_edge_gap_to(a, b, gap);
+}
+// cpp:831-923
+void PoGraph::add_edge_level(int i, int l) {
+    int u = i, v = i + 1;
+    std::vector<std::pair<int, int>> crp;
+    if (linking(u, v)) { find_common_read_pool(u, v, crp); add_dash_chain(u, v, l, crp); }
+    { auto sv = nodes[v].sib;
+      for (int s : sv) if (linking(u, s)) { find_common_read_pool(u, s, crp); add_dash_chain(u, s, l, crp); } }
+    { auto su = nodes[u].sib;
+      for (int s : su) if (linking(s, v)) { find_common_read_pool(s, v, crp); add_dash_chain(s, v, l, crp); } }
+    { auto su = nodes[u].sib; auto sv = nodes[v].sib;
+      for (int a : su) for (int b : sv)
+          if (linking(a, b)) { find_common_read_pool(a, b, crp); add_dash_chain(a, b, l, crp); } }
+}
+// cpp:925-961
+void PoGraph::delete_edge_level(int i) {
+    int u = i, v = i + 1;
+    if (linking(u, v)) del_edge(u, v);
+    for (int s : nodes[v].sib) if (linking(u, s)) del_edge(u, s);
+    for (int s : nodes[u].sib) if (linking(s, v)) del_edge(s, v);
+    for (int a : nodes[u].sib) for (int b : nodes[v].sib) if (linking(a, b)) del_edge(a, b);
+}
+
+// cpp:446-550
+void PoGraph::canonize_insert_at_level(int i) {
+    std::vector<GapEx> found;
+    find_insert_from(i, found);
+    { auto sibs = nodes[i].sib; for (int s : sibs) find_insert_from(s, found); }
+    if (found.empty()) return;
+    int n = (int)found.size();
+    std::vector<int> perm(n);
+    for (int t = 0; t < n; t++) perm[t] = t;
+    std_sort_perm(perm, [&](int a, int b) { return found[a].gap.size() > found[b].gap.size(); });
+    std::vector<GapEx> inserts(n);
+    for (int t = 0; t < n; t++) inserts[t] = std::move(found[perm[t]]);
+
+    std::vector<std::string> seqs(n);
+    int l = 0, k = 1000000000;
+    for (int t = 0; t < n; t++) {
+        for (int w : inserts[t].gap) seqs[t] += nodes[w].lab;
+        l = std::max(l, (int)seqs[t].size());
+        k = std::min(k, (int)seqs[t].size());
+    }
+    if (n == 1 || l - k == 0) {
+        add_edge_level(i, l);
+        delete_edge_level(i);
+        return;
+    }
+    std::vector<std::string> rows;
+    int ncol = msa_(seqs, rows);
+    ++msa_calls;
+    for (int t = 0; t < n; ++t) {
+        if (rows[t] != seqs[t]) {
+            int rid = 0, rcn = 0;
+            for (int w : inserts[t].gap) {
+                rid = nodes[w].pool[0].rid;
+                rcn = nodes[w].pool[0].cn;
+                delete_node(w, true);
+            }
+            std::vector<int> ng;
+            for (char ch : rows[t]) {
+                std::string lab(1, ch);
+                int w = new_node(ST_INS, lab);
+                nodes[w].pool.push_back({rid, rcn, lab});
+                ng.push_back(w);
+            }
+            add_edge_gap_to(inserts[t].u, inserts[t].v, ng);
+        }
+    }
+    add_edge_level(i, ncol);
+    delete_edge_level(i);
+}
+
+// cpp:571-622
+int PoGraph::node_level_exclude_delete(int w) {
+    std::vector<int> level_node, sub;
+    int level = 0;
+    int stamp = ++stamp_;
+    level_node.push_back(0);
+    while (!level_node.empty()) {
+        int u = level_node.back(); level_node.pop_back();
+        if (u == w) break;
+        for (int o : nodes[u].out) {
+            if (nodes[o].st == ST_DEL) continue;
+            sub.push_back(o);
+            for (int s : nodes[o].sib) sub.push_back(s);
+        }
+        if (level_node.empty()) {
+            while (!sub.empty()) {
+                int v = sub.back(); sub.pop_back();
+                if (nodes[v].stamp_a == stamp) continue;
+                level_node.push_back(v);
+                nodes[v].stamp_a = stamp;
+            }
+            level += 1;
+            stamp = ++stamp_;
+        }
+    }
+    return level;
+}
+// cpp:624-672
+void PoGraph::find_delete_from(int w, std::vector<GapEx>& out) {
+    std::vector<int> gap, st, cnt;
+    st.push_back(w); cnt.push_back(0);
+    while (!st.empty()) {
+        int u = st.back(); st.pop_back();
+        int c = cnt.back(); cnt.pop_back();
+        if (u == w) {
+            for (int o : nodes[u].out) if (nodes[o].st == ST_DEL) { st.push_back(o); cnt.push_back(0); }
+        } else if (nodes[u].st == ST_DEL) {
+            if (c == 0) {
+                st.push_back(u); cnt.push_back(1);
+                gap.push_back(u);
+                for (int o : nodes[u].out) { st.push_back(o); cnt.push_back(0); }
+            } else gap.pop_back();
+        } else {
+            out.push_back({w, u, gap});
+        }
+    }
+}
+// cpp:684-740
+void PoGraph::canonize_delete_at_level(int i) {
+    std::vector<GapEx> deletes;
+    find_delete_from(i, deletes);
+    { auto sibs = nodes[i].sib; for (int s : sibs) find_delete_from(s, deletes); }
+    if (deletes.empty()) return;
+    std::vector<std::pair<int, int>> nl;   // node -> level cache, local to this call
+    auto level_of = [&](int x) {
+        for (auto& p : nl) if (p.first == x) return p.second;
+        int lv = node_level_exclude_delete(x);
+        nl.emplace_back(x, lv);
+        return lv;
+    };
+    for (auto& d : deletes) {
+        int ul = level_of(d.u), vl = level_of(d.v);
+        int dl = vl - ul - 1, dd = (int)d.gap.size();
+        if (dl - dd > 0) {
+            int v0 = d.gap[0];
+            int rid = nodes[v0].pool[0].rid, rcn = nodes[v0].pool[0].cn;
+            std::vector<int> ng;
+            for (int t = dl - dd; t > 0; --t) {
+                int w = new_node(ST_DEL, "=");
+                nodes[w].pool.push_back({rid, rcn, "="});
+                ng.push_back(w);
+            }
+            add_edge_gap_to(d.u, v0, ng);
+            del_edge(d.u, v0);
+        }
+    }
+}
+
+// cpp:963-1005
+void PoGraph::merge_read_pool(int u, int v) {
+    auto cmp = [](const PoolEnt& a, const PoolEnt& b) {
+        if (a.rid != b.rid) return a.rid < b.rid;
+        if (a.lab != b.lab) return a.lab < b.lab;
+        return a.cn < b.cn;
+    };
+    auto& pu = nodes[u].pool;
+    auto& pv = nodes[v].pool;
+    if (!std::is_sorted(pu.begin(), pu.end(), cmp)) std::sort(pu.begin(), pu.end(), cmp);
+    if (!std::is_sorted(pv.begin(), pv.end(), cmp)) std::sort(pv.begin(), pv.end(), cmp);
+    std::vector<PoolEnt> res;
+    res.reserve(pu.size() + pv.size());
+    size_t i = 0, j = 0;
+    while (i < pu.size() && j < pv.size()) {
+        if (pu[i].rid == pv[j].rid) {
+            res.push_back({pu[i].rid, pu[i].cn, pu[i].lab + pv[j].lab});
+            i++; j++;
+        } else if (pu[i].rid < pv[j].rid) res.push_back(std::move(pu[i++]));
+        else res.push_back(std::move(pv[j++]));
+    }
+    while (i < pu.size()) res.push_back(std::move(pu[i++]));
+    while (j < pv.size()) res.push_back(std::move(pv[j++]));
+    pu.swap(res);
+}
+// cpp:1007-1038
+void PoGraph::merge_node(int u, int v) {
+    { auto vin = nodes[v].in;
+      for (int p : vin) if (!linking(p, u) && p != u) add_edge(p, u); }
+    { auto vout = nodes[v].out;
+      for (int c : vout) if (!linking(u, c) && u != c) add_edge(u, c); }
+    if (linking(u, v) && nodes[u].st == ST_MAT && nodes[v].st == ST_MAT) nodes[u].lab += nodes[v].lab;
+    merge_read_pool(u, v);
+    delete_node(v, false);
+    std::vector<PoolEnt>().swap(nodes[v].pool);
+}
+// cpp:1040-1094 / 1097-1159
+void PoGraph::directional_merge(bool backward) {
+    std::vector<int> q;
+    size_t qh = 0;
+    int st_merged = ++stamp_, st_visit = ++stamp_;
+    if (!backward) q.push_back(0);
+    else for (int i = 0; i < (int)nodes.size(); i++) if (nodes[i].alive && nodes[i].lab == "$") q.push_back(i);
+    std::vector<std::pair<int, int>> to_merge;
+    while (qh < q.size()) {
+        int w = q[qh++];
+        if (nodes[w].stamp_a == st_merged) continue;
+        {
+            const auto& adj = backward ? nodes[w].in : nodes[w].out;
+            for (size_t a = 0; a < adj.size(); a++) {
+                int u = adj[a];
+                for (size_t b = a + 1; b < adj.size(); b++) {
+                    int v = adj[b];
+                    if (u == v) continue;
+                    if (nodes[u].st == nodes[v].st && nodes[u].lab == nodes[v].lab)
+                        if (nodes[u].stamp_a != st_merged && nodes[v].stamp_a != st_merged) {
+                            to_merge.emplace_back(u, v);
+                            nodes[v].stamp_a = st_merged;
+                        }
+                }
+            }
+        }
+        for (auto& m : to_merge) merge_node(m.first, m.second);
+        to_merge.clear();
+        const auto& adj = backward ? nodes[w].in : nodes[w].out;
+        for (int c : adj)
+            if (nodes[c].stamp_b != st_visit) { q.push_back(c); nodes[c].stamp_b = st_visit; }
+    }
+}
+// cpp:1171-1216
+void PoGraph::path_collapse() {
+    int level_size = 0;
+    std::vector<int> lq, sq;
+    size_t lh = 0;
+    int stamp = ++stamp_;
+    lq.push_back(0);
+    while (lh < lq.size()) {
+        int u = lq[lh++];
+        if (level_size == 1 && nodes[u].out.size() == 1) {
+            int v = nodes[u].out[0];
+            while (nodes[v].out.size() == 1) {
+                merge_node(u, v);
+                v = nodes[u].out[0];
+            }
+        }
+        for (int v : nodes[u].out)
+            if (nodes[v].stamp_c != stamp) { sq.push_back(v); nodes[v].stamp_c = stamp; }
+        if (lh == lq.size()) {
+            lq.swap(sq); sq.clear(); lh = 0;
+            level_size = (int)lq.size();
+            stamp = ++stamp_;
+        }
+    }
+}
+// cpp:769-776 + LevelOrderIterator.cpp:3-56
+void PoGraph::node_level() {
+    std::vector<int> level_node, sub;
+    int n = 0, level = 0, stamp = ++stamp_;
+    int cur = 0, cur_level = 0;
+    for (int o : nodes[0].out) level_node.push_back(o);
+    nodes[0].stamp_a = stamp;
+    while (n != n_alive) {
+        nodes[cur].level = cur_level;
+        if (sub.empty()) { level += 1; stamp = ++stamp_; }
+        if (!level_node.empty()) {
+            int w = level_node.back(); level_node.pop_back();
+            cur = w; cur_level = level;
+            n += 1;
+            for (int o : nodes[w].out) sub.push_back(o);
+            if (level_node.empty()) {
+                while (!sub.empty()) {
+                    int x = sub.back(); sub.pop_back();
+                    if (nodes[x].stamp_a == stamp) continue;
+                    level_node.push_back(x);
+                    nodes[x].stamp_a = stamp;
+                }
+            }
+        } else n += 1;
+    }
+}
+void PoGraph::finalize_ids() {
+    order_.clear();
+    for (int i = 0; i < (int)nodes.size(); i++)
+        if (nodes[i].alive) { nodes[i].id = (int)order_.size(); order_.push_back(i); }
+}
+
+// cpp:67-265
+PoGraph::PoGraph(const std::string& G, const std::vector<AlignedRead>& R, const MsaFn& msa) : msa_(msa) {
+    const int glen = (int)G.size();
+    nodes.reserve((size_t)glen + 2 + R.size() / 2);
+    int u = new_node(ST_MAT, "^");
+    for (int i = 0; i < glen; i++) {
+        int w = new_node(ST_MAT, std::string(1, G[i]));
+        add_edge(u, w);
+        u = w;
+    }
+    int E = new_node(ST_MAT, "$");
+    add_edge(u, E);
+
+    std::vector<Cig> cig;
+    for (int rid = 0; rid < (int)R.size(); rid++) {
+        const AlignedRead& r = R[rid];
+        u = r.pos;
+        int v = r.pos + 1;
+        int i = r.pos, j = 0, dl = 0;
+        const int rlen = (int)r.seq.size();
+        cig.clear();
+        parse_cigar(r.cigar, cig);
+        for (const Cig& c : cig) {
+            if (c.op == 'S') {
+                j += j + c.len;                       // sic, cpp:126
+                dl = 0;
+                continue;
+            } else if (c.op == 'M') {
+                for (int k = 0; k < c.len + dl; k++, j++) {
+                    char rc = j < rlen ? r.seq[j] : 0;
+                    char gc = i < glen ? G[i] : 0;
+                    int st = (gc == rc) ? ST_MAT : ST_MIS;
+                    if (v >= (int)nodes.size()) throw std::runtime_error("read runs past the window");
+                    int target;
+                    if (nodes[v].st == st && nodes[v].lab.size() == 1 && nodes[v].lab[0] == rc) {
+                        target = v;
+                        if (!linking(u, v)) add_edge(u, v);
+                    } else {
+                        target = -1;
+                        for (int s : nodes[v].sib)
+                            if (nodes[s].st == st && nodes[s].lab.size() == 1 && nodes[s].lab[0] == rc) { target = s; break; }
+                        if (target < 0) {
+                            target = new_node(st, std::string(1, rc));
+                            add_edge(u, target);
+                            nodes[v].sib.push_back(target);
+                        } else if (!linking(u, target)) add_edge(u, target);
+                    }
+                    nodes[target].pool.push_back({rid, r.cn, std::string(1, rc)});
+                    u = target;
+                    v = ++i + 1;
+                }
+                dl = 0;
+            } else if (c.op == 'I') {
+                std::vector<int> gap;
+                for (int k = 0; k < c.len; k++, j++) {
+                    std::string lab(1, j < rlen ? r.seq[j] : (char)0);
+                    int w = new_node(ST_INS, lab);
+                    nodes[w].pool.push_back({rid, r.cn, lab});
+                    gap.push_back(w);
+                }
+                add_edge_gap(u, gap);
+                if (!gap.empty()) u = gap.back();
+                dl = 0;
+            } else if (c.op == 'D') {
+                std::vector<int> gap;
+                for (int k = 0; k < c.len; k++) {
+                    int w = new_node(ST_DEL, "=");
+                    nodes[w].pool.push_back({rid, r.cn, "="});
+                    gap.push_back(w);
+                    v = ++i + 1;
+                }
+                if (v >= (int)nodes.size()) throw std::runtime_error("deletion runs past the window");
+                if (nodes[v].lab == "$") {
+                    add_edge_gap_to(u, v, gap);
+                    u = v;
+                    continue;
+                }
+                add_edge_gap(u, gap);
+                if (!gap.empty()) u = gap.back();
+                dl = 0;
+            }
+        }
+        if (v >= (int)nodes.size()) throw std::runtime_error("read runs past the window");
+        if (!linking(u, v) && u != v) add_edge(u, v);
+    }
+    // canonize_graph, cpp:754-767
+    for (int i = 0; i < (int)nodes.size(); ++i) {            // canonize_insert :553-564
+        if (nodes[i].lab == "$") break;
+        canonize_insert_at_level(i);
+    }
+    for (int i = 0; i < (int)nodes.size(); ++i) {            // canonize_delete :742-752
+        if (nodes[i].lab == "$") break;
+        canonize_delete_at_level(i);
+    }
+    directional_merge(false);
+    directional_merge(true);
+    path_collapse();
+    finalize_ids();
+    node_level();
+}
+
+std::string PoGraph::dump() const {
+    std::string s;
+    char buf[64];
+    for (int i : order_) {
+        const GNode& x = nodes[i];
+        int rc = 0;
+        for (const auto& e : x.pool) rc += e.cn;
+        snprintf(buf, sizeof buf, "#\t%d\t%d\t", x.id, x.level);
+        s += buf; s += x.lab;
+        snprintf(buf, sizeof buf, "\t%d\n", rc);
+        s += buf;
+    }
+    for (int i : order_) {
+        const GNode& x = nodes[i];
+        for (int o : x.out) {
+            snprintf(buf, sizeof buf, "%d\t%d\t%d\n", x.id, nodes[o].id, reads_cover(i, o));
+            s += buf;
+        }
+    }
+    return s;
+}
+
+// ---------------------------------------------------------------------------
+void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
+    (void)n_reads;
+    static const char alpha[6] = {'A', 'C', 'G', 'T', '-', '='};
+    f.sym.assign(alpha, alpha + 6);
+    f.K = 6;
+    int code_of[256];
+    for (int i = 0; i < 256; i++) code_of[i] = -1;
+    for (int i = 0; i < 6; i++) code_of[(unsigned char)alpha[i]] = i;
+    auto code = [&](char c) -> uint8_t {
+        int& k = code_of[(unsigned char)c];
+        if (k < 0) { k = f.K++; f.sym.push_back(c); if (c == 'N') f.code_N = k; }
+        return (uint8_t)k;
+    };
+    std::vector<int> alive;
+    for (int i = 0; i < (int)g.nodes.size(); i++) if (g.nodes[i].alive) alive.push_back(i);
+    f.n_nodes = (int)alive.size();
+    f.node_lab_off.resize(f.n_nodes); f.node_lab_len.resize(f.n_nodes);
+    f.node_label_str.resize(f.n_nodes); f.node_is_end.assign(f.n_nodes, 0);
+    f.out_ptr.assign(f.n_nodes + 1, 0);
+    f.pool_ptr.assign(f.n_nodes + 1, 0);
+    for (int a = 0; a < f.n_nodes; a++) {
+        const GNode& x = g.nodes[alive[a]];
+        f.node_label_str[a] = x.lab;
+        f.node_lab_off[a] = (int)f.labels.size();
+        f.node_lab_len[a] = (int)x.lab.size();
+        bool special = (x.lab == "^" || x.lab == "$");
+        f.node_is_end[a] = (x.lab == "$");
+        for (char c : x.lab) f.labels.push_back(special ? (uint8_t)0xFF : code(c));
+        f.out_ptr[a + 1] = f.out_ptr[a] + (int)x.out.size();
+        for (int o : x.out) f.out_node.push_back(g.nodes[o].id);
+        f.pool_ptr[a + 1] = f.pool_ptr[a] + (int)x.pool.size();
+        int prev = -1;
+        for (const auto& e : x.pool) {
+            f.pool_rid.push_back(e.rid); f.pool_cn.push_back(e.cn);
+            if (e.rid < prev) f.pools_sorted = false;
+            prev = e.rid;
+        }
+    }
+    f.out_support.assign(f.out_node.size(), 0);
+
+    // level walk, NonparametricClustering.cpp:284-334 and :556-575
+    std::vector<int> level_node{0}, sub;
+    std::vector<int> visited(f.n_nodes, -1), seen_rid_level;
+    int level = 0;
+    f.level_node_ptr.push_back(0);
+    f.level_ent_ptr.push_back(0);
+    std::vector<int> rid_stamp;
+    while (!level_node.empty()) {
+        int lrc = 0, end_pos = -1;
+        for (size_t qi = 0; qi < level_node.size(); qi++) {
+            int a = level_node[qi];
+            const GNode& x = g.nodes[alive[a]];
+            f.level_nodes.push_back(a);
+            if (a == 0) {
+            } else if (f.node_is_end[a]) {
+                end_pos = (int)qi;
+            } else {
+                for (const auto& e : x.pool) {
+                    f.ent_rid.push_back(e.rid); f.ent_cn.push_back(e.cn);
+                    f.ent_node.push_back(a);
+                    f.ent_lab_off.push_back((int)f.labels.size());
+                    f.ent_lab_len.push_back((int)e.lab.size());
+                    for (char c : e.lab) f.labels.push_back(code(c));
+                    if ((int)rid_stamp.size() <= e.rid) rid_stamp.resize((size_t)e.rid + 1, -1);
+                    f.ent_first.push_back(rid_stamp[e.rid] != level);
+                    rid_stamp[e.rid] = level;
+                    lrc += e.cn;
+                    // sb single-char, rb multi-char: the reference looks up sub_count[(c,"multi")],
+                    // a key the device symbol table cannot express
+                    if (x.lab.size() == 1 && e.lab.size() > 1 && f.unsupported.empty())
+                        f.unsupported = "single-character node label with multi-character read label";
+                }
+            }
+            for (int o : x.out) {
+                int b = g.nodes[o].id;
+                if (visited[b] != level) { sub.push_back(b); visited[b] = level; }
+            }
+        }
+        f.level_node_ptr.push_back((int)f.level_nodes.size());
+        f.level_ent_ptr.push_back((int)f.ent_rid.size());
+        f.level_read_count.push_back(lrc);
+        f.level_has_end.push_back(end_pos >= 0);
+        f.level_end_pos.push_back(end_pos);
+        level += 1;
+        level_node.swap(sub);
+        sub.clear();
+    }
+    f.n_levels = level;
+    if (f.K > 8 && f.unsupported.empty()) f.unsupported = "more than 8 distinct symbols in node/read labels";
+}
+
+}  // namespace sc

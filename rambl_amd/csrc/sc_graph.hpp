@@ -1,0 +1,129 @@
+// Host side of the partial-order-graph stage of the StrainCall path.
+//
+// Builds the graph the reference builds in
+// /root/reference/StrainCall/PartialOrderGraph.cpp:67-265 (thread reads by CIGAR,
+// canonise insertions/deletions, forward/backward merge, path collapse, level
+// numbering) with index-based storage, tombstoned deletion and linear-time pool
+// intersections, then flattens it into the level-major arrays the HIP clustering
+// kernels consume (sc_kernels.hip).  The insertion MSA (row a7) is delegated to
+// the device through `MsaFn`.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace sc {
+
+enum { ST_MAT = 0, ST_MIS = 1, ST_INS = 2, ST_DEL = 3 };
+
+struct PoolEnt {
+    int rid;
+    int cn;
+    std::string lab;
+};
+
+struct GNode {
+    int st = ST_MAT;
+    std::string lab;
+    std::vector<int> in, out, sib;
+    std::vector<PoolEnt> pool;
+    bool alive = true;
+    int level = -1;
+    int id = -1;          // final id (rank among alive nodes), set by finalize_ids()
+    int stamp_a = 0, stamp_b = 0, stamp_c = 0;
+};
+
+struct AlignedRead {
+    int pos;              // 0-based offset inside the window
+    std::string cigar;
+    std::string seq;
+    int cn;               // copy number (exact duplicates collapsed upstream)
+};
+
+// rows[t] = padded row of seqs[t]; returns the number of MSA columns.
+using MsaFn = std::function<int(const std::vector<std::string>& seqs, std::vector<std::string>& rows)>;
+
+class PoGraph {
+public:
+    PoGraph(const std::string& G, const std::vector<AlignedRead>& R, const MsaFn& msa);
+
+    std::vector<GNode> nodes;
+    int n_alive = 0;
+    long msa_calls = 0;
+
+    // `-G` dump, /root/reference/StrainCall/PartialOrderGraph.cpp:318-337
+    std::string dump() const;
+    int reads_cover(int u, int v) const;   // number_of_reads_cover_nodes, cpp:1218-1244
+    int root() const { return 0; }
+
+private:
+    const MsaFn& msa_;
+    int stamp_ = 0;
+    std::vector<int> order_;   // alive node indices in `nodes` order (valid after finalize_ids)
+
+    int new_node(int st, const std::string& lab);
+    void add_edge(int u, int w);
+    void add_edge_gap(int u, const std::vector<int>& gap);
+    void add_edge_gap_to(int u, int v, const std::vector<int>& gap);
+    void del_edge(int u, int v);
+    bool linking(int u, int v) const;
+    void delete_node(int w, bool bridging);
+
+    struct GapEx { int u, v; std::vector<int> gap; };
+    void find_insert_from(int u, std::vector<GapEx>& out);
+    void find_common_read_pool(int a, int b, std::vector<std::pair<int, int>>& c);
+    void add_dash_chain(int a, int b, int l, const std::vector<std::pair<int, int>>& crp);
+    void add_edge_level(int i, int l);
+    void delete_edge_level(int i);
+    void canonize_insert_at_level(int i);
+    int node_level_exclude_delete(int w);
+    void find_delete_from(int w, std::vector<GapEx>& out);
+    void canonize_delete_at_level(int i);
+    void merge_read_pool(int u, int v);
+    void merge_node(int u, int v);
+    void directional_merge(bool backward);
+    void path_collapse();
+    void node_level();
+    void finalize_ids();
+};
+
+// libstdc++ std::sort permutation (the reference depends on its tie order at
+// PartialOrderGraph.cpp:466, NonparametricClustering.cpp:647,675, StrainCall.cpp:1027).
+// less(a,b) compares element identities a,b (values stored in idx).
+void std_sort_perm(std::vector<int>& idx, const std::function<bool(int, int)>& less);
+
+// ---------------------------------------------------------------------------
+// Level-major flattening for the device.
+struct FlatGraph {
+    // symbol table: code 0..5 = A C G T - = ; further codes in order of appearance
+    std::vector<char> sym;            // code -> char
+    int K = 6;
+    int code_N = -1;                  // code of 'N' if present
+
+    // nodes (final ids)
+    int n_nodes = 0;
+    std::vector<int> node_lab_off, node_lab_len;   // into labels[]
+    std::vector<uint8_t> labels;                   // symbol codes; 0xFF for '^' and '$'
+    std::vector<std::string> node_label_str;       // raw label text (for sequences / hashes)
+    std::vector<uint8_t> node_is_end;              // label == "$"
+    std::vector<int> out_ptr, out_node, out_support;  // CSR in out-order; support filled by the device
+
+    // level walk of NonparametricClustering.cpp:284-334 (graph-determined)
+    int n_levels = 0;
+    std::vector<int> level_node_ptr, level_nodes;  // nodes popped at each level, in order
+    std::vector<int> level_ent_ptr;                // entries (level_reads) per level
+    std::vector<int> ent_rid, ent_cn, ent_lab_off, ent_lab_len, ent_node;
+    std::vector<uint8_t> ent_first;                // first occurrence of rid within its level
+    std::vector<int> level_read_count;
+    std::vector<uint8_t> level_has_end;            // "$" popped in this level
+    std::vector<int> level_end_pos;                // index within level_nodes of the "$" pop (or -1)
+    // pools in node order for the edge-support kernel
+    std::vector<int> pool_ptr, pool_rid, pool_cn;
+    bool pools_sorted = true;
+    std::string unsupported;                       // non-empty: graph shape the device path does not model
+};
+
+void flatten(const PoGraph& g, int n_reads, FlatGraph& f);
+
+}  // namespace sc

@@ -1,0 +1,585 @@
+// HIP kernels of the StrainCall path for gfx950 (MI355X, CDNA4, wave64).
+//
+//   k_edge_support   number_of_reads_cover_nodes for every edge            (row a16)
+//   k_level          per-level read log-likelihood update (a13) followed by
+//                    the soft update (a15, hard_clustering) or the Polya-urn
+//                    sampler (a14, np_bayes_clustering; also a18, read_assign)
+//   k_msa            progressive sum-of-pairs MSA of insertion strings      (a7, a8)
+//
+// These are integer / fp64 latency- and HBM-bound loops: no MFMA.  The sampler is
+// one dependent chain per region; one wavefront runs it with one candidate strain
+// per lane (two per lane above 64), a DPP prefix scan for the categorical draw and
+// a margin test that sends near-ties to a literal fp64 evaluation of the
+// reference's formula, so every draw equals the reference's draw.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "sc_device.hpp"
+
+namespace sc {
+
+// --------------------------------------------------------------------------
+// wave64 helpers
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, BANK_MASK, BOUND);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, BANK_MASK, BOUND);
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum over the 64 lanes, in lane order
+__device__ __forceinline__ double wave_scan_incl(double v) {
+    v += dpp_f64<0x111, 0xF, 0xF, true>(v);   // row_shr:1
+    v += dpp_f64<0x112, 0xF, 0xF, true>(v);   // row_shr:2
+    v += dpp_f64<0x114, 0xF, 0xF, true>(v);   // row_shr:4
+    v += dpp_f64<0x118, 0xF, 0xF, true>(v);   // row_shr:8
+    v += dpp_f64<0x142, 0xA, 0xF, false>(v);  // row_bcast:15 -> rows 1,3
+    v += dpp_f64<0x143, 0xC, 0xF, false>(v);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ double wave_shr1(double v) {   // lane i gets lane i-1, lane 0 gets 0
+    return dpp_f64<0x138, 0xF, 0xF, true>(v);             // wave_shr:1
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// --------------------------------------------------------------------------
+// a16: support of edge e = (u -> v): PartialOrderGraph.cpp:1218-1244.
+// One wavefront per edge; pools are rid-sorted (checked on the host, `sorted`),
+// so the multiplicity of a read in u's pool comes from two binary searches.
+__global__ __launch_bounds__(256) void k_edge_support(const int* __restrict__ out_ptr, const int* __restrict__ out_node,
+                                                      const int* __restrict__ pool_ptr, const int* __restrict__ pool_rid,
+                                                      const int* __restrict__ pool_cn, const uint8_t* __restrict__ node_is_end,
+                                                      const int* __restrict__ edge_src, int n_edges, int sorted,
+                                                      int* __restrict__ support) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int e = wave; e < n_edges; e += nwaves) {
+        const int u = edge_src[e], v = out_node[e];
+        const int ub = pool_ptr[u], ue = pool_ptr[u + 1], vb = pool_ptr[v], ve = pool_ptr[v + 1];
+        long acc = 0;
+        if (u == 0) {
+            for (int j = vb + lane; j < ve; j += 64) acc += pool_cn[j];
+        } else if (node_is_end[v]) {
+            for (int i = ub + lane; i < ue; i += 64) acc += pool_cn[i];
+        } else {
+            for (int j = vb + lane; j < ve; j += 64) {
+                const int rid = pool_rid[j];
+                int mult = 0;
+                if (sorted) {
+                    int lo = ub, hi = ue;                 // lower_bound
+                    while (lo < hi) { int mid = (lo + hi) >> 1; if (pool_rid[mid] < rid) lo = mid + 1; else hi = mid; }
+                    int lo2 = lo, hi2 = ue;               // upper_bound
+                    while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (pool_rid[mid] <= rid) lo2 = mid + 1; else hi2 = mid; }
+                    mult = lo2 - lo;
+                } else {
+                    for (int i = ub; i < ue; i++) mult += (pool_rid[i] == rid);
+                }
+                acc += (long)mult * pool_cn[j];
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) support[e] = (int)acc;
+    }
+    (void)out_ptr;
+}
+
+// --------------------------------------------------------------------------
+// Literal fp64 evaluation of one categorical draw, exactly as the reference
+// forms it (NonparametricClustering.cpp:171-194 with libstdc++'s
+// discrete_distribution): executed by lane 0 of the sampling wave for the rare
+// draw whose uniform lies within the safety margin of a boundary.
+__device__ int exact_draw(const JobDev& job, const int* s_slot, const volatile double* s_a,
+                          volatile double* s_p, int S, int rid, int uid, double u) {
+    double Z = 0;
+    for (int s = 0; s < S; s++) Z += s_a[s];
+    for (int s = 0; s < S; s++) {
+        double p = s_a[s] / Z;
+        const double* row = job.ll + (long)s_slot[s] * job.ll_stride;
+        p = log(p) + (job.has[rid] ? row[rid] : 0.0);
+        if (uid >= 0 && job.has[uid]) p += row[uid];
+        s_p[s] = exp(p);
+    }
+    if (S < 2) return 0;
+    double sum = 0;
+    for (int s = 0; s < S; s++) sum += s_p[s];
+    double acc = 0;
+    for (int s = 0; s < S; s++) {
+        double pr = s_p[s] / sum;
+        acc = (s == 0) ? pr : acc + pr;
+        s_p[s] = acc;
+    }
+    s_p[S - 1] = 1.0;
+    int lo = 0, len = S;     // std::lower_bound
+    while (len > 0) {
+        int half = len >> 1, mid = lo + half;
+        if (s_p[mid] < u) { lo = mid + 1; len = len - half - 1; }
+        else len = half;
+    }
+    return lo;
+}
+
+constexpr double DRAW_EPS = 1e-10;   // relative safety margin of the fast categorical draw
+
+// The urn chain: NonparametricClustering.cpp:161-210 (and :796-829).  Runs on one
+// wavefront.  NPL strains per lane (strain index = lane*NPL + i).
+template <int NPL>
+__device__ void urn_chain(const JobDev& job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
+                          const int* s_slot, volatile double* s_a, volatile double* s_p, unsigned* s_cnt, int lane) {
+    const int S = P->S, Q = P->Q, n = P->n_sweeps;
+    constexpr int SPAD = 64 * NPL;
+    double a[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; i++) { int s = lane * NPL + i; a[i] = s < S ? P->a0[s] : 0.0; }
+    unsigned long long n_exact = 0;
+    const long total = (long)n * Q;
+    // software prefetch of the weight rows, 4 draws ahead
+    constexpr int PF = 4;
+    double rowbuf[PF][NPL];
+#pragma unroll
+    for (int d = 0; d < PF; d++) {
+        int qq = d % Q;
+#pragma unroll
+        for (int i = 0; i < NPL; i++) rowbuf[d][i] = job.tabL[(long)qq * SPAD + lane * NPL + i];
+    }
+    int q = 0, qpf = PF % Q;
+    double ublk = 0;
+    for (long t = 0; t < total; t++) {
+        if ((t & 63) == 0) ublk = (t + lane < MAX_DRAWS) ? job.U[t + lane] : 0.0;
+        const double u = readlane_f64(ublk, (int)(t & 63));
+        double L[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; i++) L[i] = rowbuf[0][i];
+#pragma unroll
+        for (int d = 0; d + 1 < PF; d++)
+#pragma unroll
+            for (int i = 0; i < NPL; i++) rowbuf[d][i] = rowbuf[d + 1][i];
+#pragma unroll
+        for (int i = 0; i < NPL; i++) rowbuf[PF - 1][i] = job.tabL[(long)qpf * SPAD + lane * NPL + i];
+        qpf = (qpf + 1 == Q) ? 0 : qpf + 1;
+
+        double w[NPL], pair = 0;
+#pragma unroll
+        for (int i = 0; i < NPL; i++) { w[i] = a[i] * L[i]; pair += w[i]; }
+        const double incl = wave_scan_incl(pair);
+        const double T = readlane_f64(incl, 63);
+        const double tgt = u * T;
+        const double lo = tgt * (1.0 - DRAW_EPS), hi = tgt * (1.0 + DRAW_EPS);
+        int c;
+        bool fast = (T > 0.0) && (T < 1.0e300) && !job.qflag[q];
+        if (NPL == 1) {
+            const unsigned long long mlo = __ballot(incl >= lo), mhi = __ballot(incl >= hi);
+            fast = fast && (mlo == mhi) && (mlo != 0ull);
+            c = fast ? (int)__builtin_ctzll(mlo) : 0;
+        } else {
+            const double E = wave_shr1(incl);
+            const double c0 = E + w[0];
+            const double c1 = E + pair;
+            const unsigned long long m0lo = __ballot(c0 >= lo), m0hi = __ballot(c0 >= hi);
+            const unsigned long long m1lo = __ballot(c1 >= lo), m1hi = __ballot(c1 >= hi);
+            fast = fast && (m0lo == m0hi) && (m1lo == m1hi) && (m1lo != 0ull);
+            int l1 = fast ? (int)__builtin_ctzll(m1lo) : 0;
+            c = 2 * l1 + (((m0lo >> l1) & 1ull) ? 0 : 1);
+        }
+        if (!fast) {
+#pragma unroll
+            for (int i = 0; i < NPL; i++) { int s = lane * NPL + i; if (s < S) s_a[s] = a[i]; }
+            __builtin_amdgcn_wave_barrier();
+            int cc = 0;
+            if (lane == 0) cc = exact_draw(job, s_slot, s_a, s_p, S, job.ent_rid[P->e0 + job.qent[q]], job.quid[q], u);
+            c = __builtin_amdgcn_readfirstlane(cc);
+            __builtin_amdgcn_wave_barrier();
+            n_exact++;
+        }
+#pragma unroll
+        for (int i = 0; i < NPL; i++) if (lane * NPL + i == c) a[i] += 1.0;
+        const int code = job.qcode[q];
+        if (lane == 0 && code < KMAX) s_cnt[c * KMAX + code] += 1u;
+        q = (q + 1 == Q) ? 0 : q + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; i++) { int s = lane * NPL + i; if (s < S) R->abund[s] = a[i]; }
+    if (lane == 0) { R->n_draws = (unsigned long long)total; R->n_exact = n_exact; }
+}
+
+// --------------------------------------------------------------------------
+// One level of the walk for one region.  Single workgroup.
+__global__ __launch_bounds__(1024) void k_level(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
+                                                int do_update) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    double* s_tab = reinterpret_cast<double*>(s_raw);            // [MAXS*KK] lpt, later the substitution histogram
+    double* s_a = s_tab + MAXS * KK;                             // [MAXS]
+    double* s_p = s_a + MAXS;                                    // [MAXS]
+    double* s_logpri = s_p + MAXS;                               // [MAXS]
+    unsigned* s_cnt = reinterpret_cast<unsigned*>(s_logpri + MAXS);   // [MAXS*KMAX]
+    int* s_slot = reinterpret_cast<int*>(s_cnt + MAXS * KMAX);   // [MAXS]
+    int* s_laboff = s_slot + MAXS;                               // [MAXS]
+    int* s_lablen = s_laboff + MAXS;                             // [MAXS]
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int S = P->S, K = job.K, e0 = P->e0, Rn = P->e1 - P->e0;
+    const long stride = job.ll_stride;
+    if (tid < S) { s_slot[tid] = P->slot[tid]; s_laboff[tid] = P->lab_off[tid]; s_lablen[tid] = P->lab_len[tid]; s_logpri[tid] = P->logpri[tid]; }
+
+    // ---- phase 0: rows of strains created by the last extension (Strain copy, Strain.cpp:73-83)
+    for (int c = 0; c < P->n_copy; c++) {
+        const double2* src = reinterpret_cast<const double2*>(job.ll + (long)P->copy_src[c] * stride);
+        double2* dst = reinterpret_cast<double2*>(job.ll + (long)P->copy_dst[c] * stride);
+        const int n2 = (job.n_reads + 1) >> 1;
+        for (int i = tid; i < n2; i += nt) dst[i] = src[i];
+        __syncthreads();                       // a later copy may read this row
+    }
+    if (tid < MAXS * KMAX) s_cnt[tid] = 0;
+    if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; }
+    __syncthreads();
+
+    // ---- phase 1: read log-likelihood update, NonparametricClustering.cpp:343-391
+    if (do_update && Rn > 0) {
+        for (int r = tid; r < Rn; r += nt) {
+            const int e = e0 + r;
+            job.isnew[r] = (job.ent_first[e] && !job.has[job.ent_rid[e]]) ? 1 : 0;
+        }
+        for (int i = tid; i < S * KK; i += nt) s_tab[i] = P->lpt[i];
+        __syncthreads();
+        const int codeN = job.code_N;
+        auto item = [&](int s, int r) {
+            const int e = e0 + r;
+            const int rid = job.ent_rid[e];
+            const uint8_t* sb = job.labels + s_laboff[s];
+            const uint8_t* rb = job.labels + job.ent_lab_off[e];
+            const int ls = s_lablen[s], lr = job.ent_lab_len[e];
+            const double* lp = s_tab + s * KK;
+            double val;
+            if (ls == 1) {
+                int a = sb[0], b = rb[0];
+                if (a == codeN) a = b;
+                val = (lr == 1 && a < K && b < K) ? lp[a * KMAX + b] : __longlong_as_double(0x7ff8000000000000ll);
+            } else {
+                val = 0.0;
+                if (job.isnew[r]) {
+                    int ii = ls, jj = lr;
+                    while (ii > 0 && jj > 0) {
+                        int a = sb[--ii], b = rb[--jj];
+                        if (a == codeN) a = b;
+                        val += lp[a * KMAX + b];
+                    }
+                } else {
+                    int ii = 0, jj = 0;
+                    while (ii < ls && jj < lr) {
+                        int a = sb[ii++], b = rb[jj++];
+                        if (a == codeN) a = b;
+                        val += lp[a * KMAX + b];
+                    }
+                }
+            }
+            double* cell = job.ll + (long)s_slot[s] * stride + rid;
+            const bool fresh = job.ent_first[e] && !job.has[rid];
+            *cell = fresh ? val : (*cell + val);            // Strain::update_read_loglik, Strain.cpp:85-95
+        };
+        if (!P->has_dups) {
+            const long total = (long)S * Rn;
+            for (long idx = tid; idx < total; idx += nt) item((int)(idx / Rn), (int)(idx % Rn));
+        } else {
+            if (tid < S) for (int r = 0; r < Rn; r++) item(tid, r);
+        }
+        __syncthreads();
+        for (int r = tid; r < Rn; r += nt) job.has[job.ent_rid[e0 + r]] = 1;
+        __syncthreads();
+    }
+    if (Rn <= 0 || S <= 0) return;
+
+    // ---- phase 2: draw slots q = (entry, copy); the reference walks copies from cn down to 1
+    const int Q = P->Q;
+    const int mode = P->mode;
+    for (int r = tid; r < Rn; r += nt) {
+        const int e = e0 + r;
+        const int rid = job.ent_rid[e], cn = job.ent_cn[e];
+        const int qb = job.ent_qoff[e];
+        const int mb = job.mate_ptr[rid], mn = job.mate_ptr[rid + 1] - mb;
+        const uint8_t code = (job.ent_lab_len[e] == 1) ? job.labels[job.ent_lab_off[e]] : (uint8_t)0xFF;
+        for (int i = 0; i < cn; i++) {
+            const int k = cn - 1 - i;
+            const int uid = (k < mn) ? job.mate_idx[mb + k] : -1;
+            job.qent[qb + i] = r;
+            job.quid[qb + i] = uid;
+            job.qcode[qb + i] = code;
+        }
+    }
+    __syncthreads();
+
+    if (mode == MODE_HARD) {
+        // hard_clustering, NonparametricClustering.cpp:17-125
+        // logprob(uid) inserts a zero log-likelihood for a mate not seen yet (Strain.cpp:147-150)
+        for (int q = tid; q < Q; q += nt) {
+            const int uid = job.quid[q];
+            if (uid >= 0 && !job.has[uid])
+                for (int s = 0; s < S; s++) job.ll[(long)s_slot[s] * stride + uid] = 0.0;
+        }
+        __syncthreads();
+        for (int q = tid; q < Q; q += nt) { const int uid = job.quid[q]; if (uid >= 0) job.has[uid] = 1; }
+        __syncthreads();
+        for (int q = tid; q < Q; q += nt) {
+            const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
+            double norm = 0;
+            for (int s = 0; s < S; s++) {
+                const double* row = job.ll + (long)s_slot[s] * stride;
+                double x = s_logpri[s] + row[rid];
+                if (uid >= 0) x += row[uid];
+                const double p = exp(x);
+                job.tabA[(long)s * job.qcap + q] = p;
+                norm += p;
+            }
+            for (int s = 0; s < S; s++) job.tabA[(long)s * job.qcap + q] /= norm;
+        }
+        for (int i = tid; i < S * KK; i += nt) s_tab[i] = 0.0;
+        __syncthreads();
+        if (!P->any_multi) {
+            // thread (s, b): responsibilities summed in draw-slot order, as the reference adds them
+            for (int idx = tid; idx < S * (K + 1); idx += nt) {
+                const int s = idx / (K + 1), b = idx % (K + 1);
+                const double* prow = job.tabA + (long)s * job.qcap;
+                double acc = 0;
+                if (b == K) {
+                    for (int q = 0; q < Q; q++) acc += prow[q];
+                    R->abund[s] = acc;
+                } else {
+                    for (int q = 0; q < Q; q++) if (job.qcode[q] == b) acc += prow[q];
+                    const int a = job.labels[s_laboff[s]];
+                    s_tab[s * KK + a * KMAX + b] = acc;
+                }
+            }
+        } else {
+            if (tid < S) {
+                const int s = tid;
+                const double* prow = job.tabA + (long)s * job.qcap;
+                double* hist = s_tab + s * KK;
+                const uint8_t* sb = job.labels + s_laboff[s];
+                const int ls = s_lablen[s];
+                double acc = 0;
+                for (int q = 0; q < Q; q++) {
+                    const double p = prow[q];
+                    acc += p;
+                    const int r = job.qent[q], e = e0 + r;
+                    const uint8_t* rb = job.labels + job.ent_lab_off[e];
+                    const int lr = job.ent_lab_len[e];
+                    if (lr == 1) {
+                        if (ls == 1) hist[sb[0] * KMAX + rb[0]] += p;
+                    } else if (job.isnew[r]) {
+                        int i = ls, j = lr;
+                        while (i > 0 && j > 0) { int a = sb[--i], b = rb[--j]; hist[a * KMAX + b] += p; }
+                    } else {
+                        int i = 0, j = 0;
+                        while (i < ls && j < lr) { int a = sb[i++], b = rb[j++]; hist[a * KMAX + b] += p; }
+                    }
+                }
+                R->abund[s] = acc;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < S * KK; i += nt) R->subst[i] = s_tab[i];
+        return;
+    }
+
+    // ---- MODE_SAMPLE: np_bayes_clustering / read_assign
+    if (P->n_sweeps <= 0 || S == 1) return;           // nothing to draw (host handles S == 1 and n == 0)
+    const int SPAD = (S <= 64) ? 64 : 128;
+    for (long idx = tid; idx < (long)S * Q; idx += nt) {
+        const int s = (int)(idx / Q), q = (int)(idx % Q);
+        const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
+        const double* row = job.ll + (long)s_slot[s] * stride;
+        double x = job.has[rid] ? row[rid] : 0.0;
+        if (uid >= 0 && job.has[uid]) x += row[uid];
+        job.tabA[(long)s * job.qcap + q] = x;
+    }
+    __syncthreads();
+    for (int q = tid; q < Q; q += nt) {
+        double m = -INFINITY;
+        for (int s = 0; s < S; s++) m = fmax(m, job.tabA[(long)s * job.qcap + q]);
+        job.qflag[q] = (m >= -600.0) ? 0 : 1;             // also catches NaN / -inf
+        double* Lr = job.tabL + (long)q * SPAD;
+        for (int s = 0; s < S; s++) Lr[s] = exp(job.tabA[(long)s * job.qcap + q] - m);
+        for (int s = S; s < SPAD; s++) Lr[s] = 0.0;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        if (SPAD == 64) urn_chain<1>(job, P, R, s_slot, s_a, s_p, s_cnt, tid);
+        else urn_chain<2>(job, P, R, s_slot, s_a, s_p, s_cnt, tid);
+        __builtin_amdgcn_wave_barrier();
+        for (int i = tid; i < S * KMAX; i += 64) R->cnt[i] = s_cnt[i];
+    }
+}
+
+// --------------------------------------------------------------------------
+// a7/a8: progressive sum-of-pairs MSA, MultipleSequenceAlignmentSP.cpp:10-301,
+// scored with SimpleDnaScore (SimpleDnaScore.cpp:15-42, Score.hpp:35).
+//
+// The per-row gap memory PP of the reference is uniform over the rows of a cell
+// everywhere except in column j = 0 (its writers never advance the row iterator,
+// :208-217/:235-245), so the three sum-of-pairs candidates of a cell reduce to
+// dot products of the column's character counts with the score table.  The DP of
+// one progressive step runs on one wavefront: lane j owns DP column j and the
+// (i-1,j-1)/(i,j-1) dependencies arrive from lane j-1 through a lane shift, one
+// anti-diagonal per iteration.  All values are small integers (exact in int32).
+__device__ __forceinline__ int cls_of(char c) {
+    switch (c) {
+        case 'A': return 0; case 'a': return 1; case 'C': return 2; case 'c': return 3;
+        case 'G': return 4; case 'g': return 5; case 'T': return 6; case 't': return 7;
+        case '+': return 8; case '-': return 9; default: return 10;
+    }
+}
+__device__ __forceinline__ int dna_score_cls(int x, int y) {
+    if (x > 9 || y > 9) return 0;                 // std::map operator[] on a missing key
+    if (x == y) return 3;
+    if (x < 8 && y < 8 && (x >> 1) == (y >> 1)) return 3;
+    if ((x == 8 && y == 9) || (x == 9 && y == 8)) return 3;
+    if (x == 8 || y == 8) return -6;              // gap_open + gap_extend
+    if (x == 9 || y == 9) return -2;              // gap_extend
+    return -5;
+}
+
+
+__global__ __launch_bounds__(256) void k_msa(MsaDev d) {
+    __shared__ int s_ncol, s_newn, s_err;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+    const int n = d.n;
+    int cur = 0;
+    if (tid == 0) { s_ncol = d.seq_off[1] - d.seq_off[0]; s_err = 0; }
+    __syncthreads();
+    {   // first sequence: one column per character
+        const int l0 = s_ncol;
+        for (int c = tid; c < l0; c += nt) {
+            d.cols[0][(long)c * n + 0] = d.seqs[d.seq_off[0] + c];
+            for (int k = 0; k < 11; k++) d.counts[c * 11 + k] = 0;
+            d.counts[c * 11 + cls_of(d.seqs[d.seq_off[0] + c])] = 1;
+        }
+    }
+    __syncthreads();
+    for (int t = 1; t < n; t++) {
+        const int s = t;                                  // rows already aligned
+        const int ncol = s_ncol;
+        const int m = ncol + 1;
+        const char* seq = d.seqs + d.seq_off[t];
+        const int len = d.seq_off[t + 1] - d.seq_off[t];
+        const int nn = len + 1;
+        if (nn > 64 || ncol + len > d.cmax) { if (tid == 0) s_err = 1; __syncthreads(); break; }
+        const char* colc = d.cols[cur];
+        // ---- forward, wave 0: lane j = DP column j, time step tau handles row i = tau - j
+        if (tid < 64) {
+            const int j = lane;
+            const int b = (j >= 1 && j < nn) ? cls_of(seq[j - 1]) : 10;
+            // column j = 0 boundary values are produced by lane 0 as it walks i
+            int sc_up = 0;          // SC[i-1][j]
+            int st_up = 0;          // state of cell (i-1, j): 0 mat, 1 ins, 2 del
+            // row 0: SC[0][j] = s*(-6) + (j-1)*s*(-2), state ins for j >= 1, mat at j = 0
+            if (j >= 1) { sc_up = s * (-6) + (j - 1) * s * (-2); st_up = 1; }
+            int sc_left_prev = 0, st_left_prev = 0;   // cell (i-1, j-1) as delivered last step
+            for (int tau = 1; tau < m + nn - 1; tau++) {
+                const int i = tau - j;
+                // values of cell (i, j-1) computed by lane j-1 in the previous step
+                const int sc_l = __shfl_up(sc_up, 1);      // lane j-1's current (i, j-1) sits in its sc_up
+                const int st_l = __shfl_up(st_up, 1);
+                int sc_new = sc_up, st_new = st_up;
+                if (i >= 1 && i < m && j < nn) {
+                    const int* cnt = d.counts + (i - 1) * 11;
+                    if (j == 0) {
+                        int sp = 0;
+                        const int y = (i == 1) ? 8 : 9;
+                        for (int c = 0; c < 10; c++) sp += cnt[c] * dna_score_cls(c, y);
+                        sc_new = sc_up + sp;
+                        st_new = 3;                       // per-row state, never ins and never uniform-del
+                        d.moves[i * 64 + 0] = 2;
+                    } else {
+                        const int nd = cnt[9];
+                        const char c0 = colc[(long)(i - 1) * n + 0];
+                        // diagonal: cell (i-1, j-1)
+                        int r1 = 0;
+                        for (int c = 0; c < 9; c++) r1 += cnt[c] * dna_score_cls(c, b);
+                        r1 += nd * dna_score_cls(st_left_prev == 1 ? 9 : 8, b);
+                        r1 += sc_left_prev;
+                        // insert: cell (i, j-1)
+                        int r2 = s * dna_score_cls(st_l == 1 ? 9 : 8, b) + sc_l;
+                        // delete: cell (i-1, j)
+                        int r3 = 0;
+                        const int y3 = (st_up == 2) ? 9 : 8;
+                        for (int c = 0; c < 9; c++) r3 += cnt[c] * dna_score_cls(c, y3);
+                        r3 += nd * 3;                     // score('-','-')
+                        r3 += sc_up;
+                        if (r1 >= r2 && r1 >= r3) { sc_new = r1; st_new = (c0 == '-') ? 1 : 0; d.moves[i * 64 + j] = 0; }
+                        else if (r2 >= r1 && r2 >= r3) { sc_new = r2; st_new = 1; d.moves[i * 64 + j] = 1; }
+                        else { sc_new = r3; st_new = (c0 == '-') ? 0 : 2; d.moves[i * 64 + j] = 2; }
+                    }
+                }
+                // what lane j-1 held BEFORE this step is cell (i-1, j-1) for the next step
+                sc_left_prev = sc_l; st_left_prev = st_l;
+                if (i >= 1 && i < m && j < nn) { sc_up = sc_new; st_up = st_new; }
+            }
+        }
+        __syncthreads();
+        // ---- traceback, MultipleSequenceAlignmentSP.cpp:252-301 (thread 0)
+        if (tid == 0) {
+            int x = m - 1, y = nn - 1, cnt = 0;
+            int r1 = ncol - 1, r2 = len - 1;
+            while (!(x == 0 && y == 0)) {
+                int mv;
+                if (x == 0) mv = 1; else if (y == 0) mv = 2; else mv = d.moves[x * 64 + y];
+                if (mv == 0) { d.trace[2 * cnt] = r1; d.trace[2 * cnt + 1] = r2; --r1; --r2; --x; --y; }
+                else if (mv == 1) { d.trace[2 * cnt] = -1; d.trace[2 * cnt + 1] = r2; --r2; --y; }
+                else { d.trace[2 * cnt] = r1; d.trace[2 * cnt + 1] = -1; --r1; --x; }
+                cnt++;
+            }
+            s_newn = cnt;
+        }
+        __syncthreads();
+        // ---- rebuild columns (reversed traceback order) and their counts
+        const int newn = s_newn;
+        char* coln = d.cols[cur ^ 1];
+        for (long idx = tid; idx < (long)newn * (s + 1); idx += nt) {
+            const int c = (int)(idx / (s + 1)), k = (int)(idx % (s + 1));
+            const int src = d.trace[2 * (newn - 1 - c)], sj = d.trace[2 * (newn - 1 - c) + 1];
+            char ch;
+            if (k < s) ch = (src >= 0) ? colc[(long)src * n + k] : '-';
+            else ch = (sj >= 0) ? seq[sj] : '-';
+            coln[(long)c * n + k] = ch;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < newn * 11; idx += nt) d.counts[idx] = 0;
+        __syncthreads();
+        for (int c = tid; c < newn; c += nt) {
+            int loc[11];
+            for (int k = 0; k < 11; k++) loc[k] = 0;
+            for (int k = 0; k <= s; k++) loc[cls_of(coln[(long)c * n + k])]++;
+            for (int k = 0; k < 11; k++) d.counts[c * 11 + k] = loc[k];
+        }
+        if (tid == 0) s_ncol = newn;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (tid == 0) { *d.ncol_out = s_ncol; *d.err_out = s_err | (cur << 8); }
+}
+
+// --------------------------------------------------------------------------
+// host-callable launchers (called from sc_cluster.cpp / sc_api.cpp)
+void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node, const int* pool_ptr, const int* pool_rid,
+                         const int* pool_cn, const uint8_t* node_is_end, const int* edge_src, int n_edges, int sorted,
+                         int* support) {
+    if (n_edges <= 0) return;
+    int waves_per_block = 4;
+    int blocks = (n_edges + waves_per_block - 1) / waves_per_block;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_edge_support, dim3(blocks), dim3(256), 0, st, out_ptr, out_node, pool_ptr, pool_rid, pool_cn,
+                       node_is_end, edge_src, n_edges, sorted, support);
+}
+constexpr size_t LEVEL_LDS = sizeof(double) * (MAXS * KK + 3 * MAXS) + sizeof(unsigned) * MAXS * KMAX + sizeof(int) * 3 * MAXS;
+int init_kernels() {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEVEL_LDS);
+}
+void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int do_update) {
+    hipLaunchKernelGGL(k_level, dim3(1), dim3(1024), LEVEL_LDS, st, job, P, R, do_update);
+}
+void launch_msa(hipStream_t st, const MsaDev& d) { hipLaunchKernelGGL(k_msa, dim3(1), dim3(256), 0, st, d); }
+
+}  // namespace sc

@@ -1,0 +1,200 @@
+"""Text that crosses the samtools boundary of the StrainCall path.
+
+The reference shells out to samtools 0.1.19 four times per window
+(/root/reference/StrainCall/StrainCall.cpp:167 faidx, :496 view, :696 mpileup,
+:229/:256 faidx for the index).  Only a few whitespace-separated fields of that
+text are read.  This module produces the same text either
+
+* natively, when the alignment file is SAM *text* (so benchmarks and tests do not
+  depend on an external tool), or
+* by running the real `samtools` with the reference's exact command lines when the
+  alignment file is BAM (drop-in behaviour under scripts/rambl.py).
+
+FASTA access is always native (a FASTA record is plain text).
+"""
+import re
+import shutil
+import subprocess
+
+_CIG = re.compile(r"(\d+)([MIDNSHP=X])")
+
+
+class SamtoolsMissing(RuntimeError):
+    pass
+
+
+def is_bam(path):
+    try:
+        with open(path, "rb") as f:
+            return f.read(2) == b"\x1f\x8b"
+    except OSError:
+        return False
+
+
+def _run_samtools(args):
+    exe = shutil.which("samtools")
+    if exe is None:
+        raise SamtoolsMissing("`samtools` is needed to read BAM input (%s) and is not on PATH; "
+                              "pass SAM text instead" % " ".join(args))
+    p = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    return p.stdout.decode("ascii", "replace").splitlines()
+
+
+def parse_region(reg):
+    if ":" in reg:
+        name, span = reg.rsplit(":", 1)
+        a, b = span.split("-")
+        return name, int(a), int(b)
+    return reg, None, None
+
+
+class Fasta:
+    """Whole-file FASTA reader (seed-gene files are a few MB)."""
+
+    def __init__(self, path):
+        self.path = path
+        self.seqs = {}
+        self.order = []
+        name = None
+        chunks = None
+        with open(path) as f:
+            for line in f:
+                line = line.rstrip("\r\n")
+                if line.startswith(">"):
+                    if name is not None:
+                        self.seqs[name] = "".join(chunks)
+                    name = line[1:].split()[0] if len(line) > 1 else ""
+                    chunks = []
+                    self.order.append(name)
+                elif name is not None:
+                    chunks.append(line)
+        if name is not None:
+            self.seqs[name] = "".join(chunks)
+
+    def fetch(self, region):
+        """Sequence text `samtools faidx fa region` would print (header removed)."""
+        name, a, b = parse_region(region)
+        if name not in self.seqs and region in self.seqs:
+            name, a, b = region, None, None
+        s = self.seqs.get(name, "")
+        if a is not None:
+            s = s[max(0, a - 1):b]
+        return s
+
+
+def read_fai(path):
+    """[(name, length)] from <fasta>.fai: fields 1-2 (StrainCall.cpp:233-270)."""
+    out = []
+    with open(path) as f:
+        for line in f:
+            fld = line.split()
+            if fld:
+                out.append((fld[0], fld[1] if len(fld) > 1 else ""))
+    return out
+
+
+def _ref_span(pos, cigar):
+    n = 0
+    for ln, op in _CIG.findall(cigar):
+        if op in "MDN=X":
+            n += int(ln)
+    return pos, pos + max(n, 1) - 1
+
+
+class SamText:
+    """A SAM text file held in memory, indexed by reference name."""
+
+    def __init__(self, path):
+        self.path = path
+        self.by_ref = {}
+        with open(path) as f:
+            for line in f:
+                if line.startswith("@") or not line.strip():
+                    continue
+                line = line.rstrip("\r\n")
+                fld = line.split("\t")
+                if len(fld) < 11:
+                    continue
+                self.by_ref.setdefault(fld[2], []).append((line, fld))
+
+    def view(self, mq, fmask, region):
+        name, a0, b0 = parse_region(region)
+        out = []
+        for line, f in self.by_ref.get(name, ()):
+            if int(f[1]) & fmask:
+                continue
+            if int(f[4]) < mq:
+                continue
+            if a0 is not None:
+                s, e = _ref_span(int(f[3]), f[5])
+                if e < a0 or s > b0:
+                    continue
+            out.append(line)
+        return out
+
+    def mpileup(self, mq, region):
+        """Lines of `samtools mpileup -q mq -Q0 -A -r region`; only fields 2 and 5
+        are consumed downstream (StrainCall.cpp:712-735)."""
+        name, a0, b0 = parse_region(region)
+        cols = {}
+        for line, f in self.by_ref.get(name, ()):
+            flag = int(f[1])
+            if flag & 1796 or int(f[4]) < mq:
+                continue
+            pos, seq = int(f[3]), f[9]
+            s, e = _ref_span(pos, f[5])
+            if a0 is not None and (e < a0 or s > b0):
+                continue
+            rev = bool(flag & 16)
+            ops = [(int(n), op) for n, op in _CIG.findall(f[5]) if op not in "HP"]
+            mapq_ch = chr(33 + min(int(f[4]), 93))
+            j, p, first = 0, pos, True
+            for k, (n, op) in enumerate(ops):
+                if op == "S":
+                    j += n
+                elif op in "M=X":
+                    for t in range(n):
+                        if a0 is None or a0 <= p <= b0:
+                            b = seq[j].lower() if rev else seq[j].upper()
+                            txt = ("^" + mapq_ch if first else "") + b
+                            if t == n - 1 and k + 1 < len(ops):
+                                n2, op2 = ops[k + 1]
+                                if op2 == "I":
+                                    ins = seq[j + 1:j + 1 + n2]
+                                    txt += "+%d%s" % (n2, ins.lower() if rev else ins.upper())
+                                elif op2 == "D":
+                                    txt += "-%d%s" % (n2, ("n" if rev else "N") * n2)
+                            if p == e:
+                                txt += "$"
+                            cols.setdefault(p, []).append(txt)
+                        first = False
+                        j += 1
+                        p += 1
+                elif op == "I":
+                    j += n
+                elif op in "DN":
+                    for t in range(n):
+                        if a0 is None or a0 <= p <= b0:
+                            cols.setdefault(p, []).append("*" + ("$" if p == e else ""))
+                        p += 1
+        return ["%s\t%d\tN\t%d\t%s\t%s" % (name, p, len(cols[p]), "".join(cols[p]), "I" * len(cols[p]))
+                for p in sorted(cols)]
+
+
+class Alignments:
+    """view/mpileup provider for a mapping file (SAM text or BAM)."""
+
+    def __init__(self, path):
+        self.path = path
+        self.bam = is_bam(path)
+        self.sam = None if self.bam else SamText(path)
+
+    def view(self, mq, region):
+        if self.bam:   # StrainCall.cpp:496
+            return _run_samtools(["view", self.path, "-q", str(mq), "-F", "1804", region])
+        return self.sam.view(mq, 1804, region)
+
+    def mpileup(self, mq, region):
+        if self.bam:   # StrainCall.cpp:696
+            return _run_samtools(["mpileup", "-q", str(mq), "-Q0", "-A", "-r", region, self.path])
+        return self.sam.mpileup(mq, region)
