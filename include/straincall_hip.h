@@ -60,6 +60,7 @@ typedef struct sc_stats {
     double cluster_ms;        /* level walk incl. kernels */
     double sampler_kernel_ms; /* sum of HIP-event times of the SAMPLE-mode launches */
     long sampler_launches;
+    long sampler_read_copies; /* sum over SAMPLE launches of the read copies (draw slots) of the level */
     long level_launches;
     long draws;               /* categorical draws made on the device */
     long exact_draws;         /* of which resolved by the literal fp64 path */

@@ -369,7 +369,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     bool branching = false;
     std::vector<std::pair<int, int>> pending_copies;     // (src slot, dst slot) for the next launch
     double sampler_ms = 0;
-    long sampler_launches = 0, level_launches = 0, draws = 0, exact = 0;
+    long sampler_launches = 0, level_launches = 0, draws = 0, exact = 0, sampler_copies = 0;
 
     auto run_level = [&](int mode, int e0, int e1, int Q, int n_sweeps, bool do_update, const std::vector<HStrain>& sv,
                          bool has_dups, bool any_multi) {
@@ -404,7 +404,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         if (timed) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
-            sampler_ms += ms; sampler_launches++;
+            sampler_ms += ms; sampler_launches++; sampler_copies += Q;
             draws += (long)Rh->n_draws; exact += (long)Rh->n_exact;
         }
     };
@@ -619,6 +619,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     }
     job.stats.sampler_kernel_ms = sampler_ms;
     job.stats.sampler_launches = sampler_launches;
+    job.stats.sampler_read_copies = sampler_copies;
     job.stats.level_launches = level_launches;
     job.stats.draws = draws;
     job.stats.exact_draws = exact;

@@ -1,0 +1,183 @@
+"""Stage 5 of rambl.py (strain-level assembly) for one node of MI355X GPUs.
+
+Mirror of /root/reference/scripts/rambl.py:169-201 (`strain_call`) and :236-238
+(the `seqtk seq -L 400` length filter): the region list comes from
+`seed_otus.fasta.fai` (`name:1-len` per record), every region is one independent
+StrainCall run with rambl.py's option defaults (:260-271), the per-region FASTA
+files are concatenated in .fai order.
+
+The reference fans regions out over a process pool; here one process drives one
+GPU with several regions in flight (one HIP stream each), regions are sharded
+over ranks longest-processing-time-first, nothing is exchanged while they run,
+and the only collective is the final gather of FASTA bytes to rank 0 in .fai
+order (torch.distributed: RCCL over xGMI on GPUs, gloo in CPU tests).
+"""
+import os
+
+import numpy as np
+
+from . import cli, ingest, samio
+
+RAMBL_DEFAULTS = dict(map_qual=0, max_depth=800, max_ins=13, read_len=70, tau=0.02, diff_rate=0.02)
+
+
+def roi_list(fai_path):
+    """rambl.py:172-175."""
+    rois = []
+    with open(fai_path) as f:
+        for line in f:
+            field = line.split()
+            if field:
+                rois.append("%s:1-%s" % (field[0], field[1]))
+    return rois
+
+
+def straincall_argv(roi, fasta, bam, opts=None):
+    """rambl.py:181-187."""
+    o = dict(RAMBL_DEFAULTS)
+    o.update(opts or {})
+    return ["-r", str(roi), "-q", str(o["map_qual"]), "-D", str(o["max_depth"]), "-I", str(o["max_ins"]),
+            "-l", str(o["read_len"]), "-t", str(o["tau"]), "-d", str(o["diff_rate"]), "-w", str(5000), fasta, bam]
+
+
+def lpt_shards(costs, n):
+    """Longest-processing-time-first partition of unit indices over n ranks."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0.0] * n
+    shards = [[] for _ in range(n)]
+    for i in order:
+        r = min(range(n), key=lambda k: (load[k], k))
+        shards[r].append(i)
+        load[r] += costs[i]
+    return shards
+
+
+def seqtk_L(fasta_text, min_len=400):
+    """`seqtk seq -L 400` on the concatenated result (rambl.py:236-238)."""
+    out = []
+    name = None
+    seq = []
+    for line in fasta_text.splitlines():
+        if line.startswith(">"):
+            if name is not None and len("".join(seq)) >= min_len:
+                out.append(name + "\n" + "".join(seq) + "\n")
+            name, seq = line, []
+        elif name is not None:
+            seq.append(line.strip())
+    if name is not None and len("".join(seq)) >= min_len:
+        out.append(name + "\n" + "".join(seq) + "\n")
+    return "".join(out)
+
+
+def prepare_region(roi, fasta, bam, opts=None, shared=None):
+    """argv -> [(window, RegionReads)] (host ingest, rows a1-a4)."""
+    pa = cli.parse_cmd_line(straincall_argv(roi, fasta, bam, opts))
+    if shared is None:
+        return pa, cli.load_regions(pa)
+    fa, fai, aln = shared
+    windows = ingest.make_scan_window(pa, fai, aln)
+    out = []
+    for gn, p0, p1 in windows:
+        r = "%s:%d-%d" % (gn, p0, p1)
+        out.append(((gn, p0, p1), ingest.load_mapping_reads(fa.fetch(r), aln, pa.mapping_qual, pa.read_len, pa.max_ins,
+                                                            pa.max_depth, r)))
+    return pa, out
+
+
+def run_regions(ctx, prepared, streams=1):
+    """prepared: list of (pa, [(window, reads)]).  Submits every window, `streams`
+    in flight, returns the FASTA text of each entry of `prepared`."""
+    from . import capi
+    texts = [[] for _ in prepared]
+    pending = []
+    stats = []
+
+    def drain(k):
+        while len(pending) > k:
+            idx, wi, window, pa, h = pending.pop(0)
+            res = ctx.wait(h)
+            texts[idx].append((wi, cli.format_fasta(window, res, pa.tau)))
+            stats.append(res.stats)
+
+    for idx, (pa, regs) in enumerate(prepared):
+        params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate))
+        for wi, (window, reads) in enumerate(regs):
+            if len(reads) == 0:
+                continue
+            pending.append((idx, wi, window, pa, ctx.submit(reads, params)))
+            drain(max(streams, 1))
+    drain(0)
+    return ["".join(t for _, t in sorted(x)) for x in texts], stats
+
+
+def gather_fasta(local_texts, local_ids, n_units, dist=None, device=None):
+    """Variable-length gather of per-region FASTA bytes to rank 0, returned in
+    unit order (replaces `cat` in rambl.py:197-201).  dist=None: single process."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        out = [""] * n_units
+        for i, t in zip(local_ids, local_texts):
+            out[i] = t
+        return "".join(out)
+    import torch
+    world = dist.get_world_size()
+    dev = device if device is not None else torch.device("cpu")
+    blob = bytearray()
+    index = []
+    for i, t in zip(local_ids, local_texts):
+        b = t.encode("ascii")
+        index += [i, len(b)]
+        blob += b
+    meta = torch.tensor([len(index) // 2, len(blob)], dtype=torch.int64, device=dev)
+    metas = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    max_units = int(max(int(m[0]) for m in metas))
+    max_bytes = int(max(int(m[1]) for m in metas))
+    idx_t = torch.full((2 * max(max_units, 1),), -1, dtype=torch.int64, device=dev)
+    if index:
+        idx_t[:len(index)] = torch.tensor(index, dtype=torch.int64, device=dev)
+    pay = torch.zeros(max(max_bytes, 1), dtype=torch.uint8, device=dev)
+    if blob:
+        pay[:len(blob)] = torch.tensor(np.frombuffer(bytes(blob), dtype=np.uint8).copy(), dtype=torch.uint8, device=dev)
+    idxs = [torch.empty_like(idx_t) for _ in range(world)]
+    pays = [torch.empty_like(pay) for _ in range(world)]
+    dist.all_gather(idxs, idx_t)
+    dist.all_gather(pays, pay)
+    if dist.get_rank() != 0:
+        return None
+    out = [""] * n_units
+    for r in range(world):
+        ix = idxs[r].cpu().tolist()
+        data = pays[r].cpu().numpy().tobytes()
+        off = 0
+        for k in range(int(metas[r][0])):
+            u, ln = ix[2 * k], ix[2 * k + 1]
+            out[u] = data[off:off + ln].decode("ascii")
+            off += ln
+    return "".join(out)
+
+
+def strain_call(fasta, bam, out_dir=None, prefix="rambl", opts=None, device=0, streams=4, dist=None, torch_device=None):
+    """rambl.py `strain_call` for this rank's shard; rank 0 returns the concatenated
+    FASTA (and writes <out_dir>/3_straincall_results/<roi>.fa + <prefix>.fa)."""
+    from . import capi
+    rois = roi_list(fasta + ".fai")
+    fai = samio.read_fai(fasta + ".fai")
+    costs = [float(ingest.stoi(l)) for _, l in fai]
+    world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+    mine = lpt_shards(costs, world)[rank]
+    shared = (samio.Fasta(fasta), fai, samio.Alignments(bam))
+    prepared = [prepare_region(rois[i], fasta, bam, opts, shared) for i in mine]
+    with capi.Context(device, streams) as ctx:
+        texts, _ = run_regions(ctx, prepared, streams)
+    if out_dir is not None:
+        sc_dir = os.path.join(out_dir, "3_straincall_results")
+        os.makedirs(sc_dir, exist_ok=True)
+        for i, t in zip(mine, texts):
+            with open(os.path.join(sc_dir, "%s.fa" % rois[i]), "w") as f:
+                f.write(t)
+    full = gather_fasta(texts, mine, len(rois), dist, torch_device)
+    if rank == 0 and out_dir is not None:
+        with open(os.path.join(out_dir, "%s.fa" % prefix), "w") as f:
+            f.write(full)
+    return full
