@@ -135,7 +135,13 @@ def main():
             "breakdown_ms_per_step": {"graph_host": sum(s["graph_ms"] for s in all_stats) / a.steps,
                                       "level_walk": sum(s["cluster_ms"] for s in all_stats) / a.steps,
                                       "sampler_kernels": k_ms / a.steps,
-                                      "exact_draws": sum(s["exact_draws"] for s in all_stats) / a.steps},
+                                      "draws": draws / a.steps,
+                                      "slow_tier_draws": sum(s["slow_draws"] for s in all_stats) / a.steps,
+                                      "exact_draws": sum(s["exact_draws"] for s in all_stats) / a.steps,
+                                      "redo_blocks": sum(s["redo_blocks"] for s in all_stats) / a.steps,
+                                      "chain_cycles_per_draw": sum(s["chain_cycles"] for s in all_stats) / max(draws, 1),
+                                      "chain_ns_per_draw": 10.0 * sum(s["chain_wall_ticks"] for s in all_stats) / max(draws, 1),
+                                      "avg_candidates_per_sampler_launch": sum(s["sampler_strains"] for s in all_stats) / max(k_n, 1)},
             "contigs": fasta_out.count(">") if fasta_out else 0,
         }
         if not a.no_cpu:

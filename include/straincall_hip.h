@@ -63,7 +63,12 @@ typedef struct sc_stats {
     long sampler_read_copies; /* sum over SAMPLE launches of the read copies (draw slots) of the level */
     long level_launches;
     long draws;               /* categorical draws made on the device */
+    long slow_draws;          /* of which needed the fp64 scan tier */
     long exact_draws;         /* of which resolved by the literal fp64 path */
+    long sampler_strains;     /* sum over SAMPLE launches of the candidate count */
+    long redo_blocks;         /* 32-draw blocks replayed through the checked tiers */
+    long chain_cycles;        /* shader cycles spent inside the urn chains */
+    long chain_wall_ticks;    /* the same in 100 MHz ticks */
     long msa_calls;
     int n_nodes, n_levels, n_unique_reads;
     long n_read_copies;

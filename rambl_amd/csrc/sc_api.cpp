@@ -156,7 +156,7 @@ struct Worker {
     LevelResult* Rh = nullptr;        // host-mapped, written by the kernel
     LevelResult* Rd = nullptr;
     DevBuf b_ent_rid, b_ent_cn, b_ent_lab_off, b_ent_lab_len, b_ent_first, b_ent_qoff, b_labels, b_mate_ptr, b_mate_idx,
-        b_ll, b_has, b_isnew, b_tabA, b_tabL, b_qflag, b_qcode, b_qent, b_quid, b_out_ptr, b_out_node, b_pool_ptr, b_pool_rid,
+        b_ll, b_has, b_isnew, b_tabA, b_tabL, b_tabLf, b_qflag, b_qcode, b_qent, b_quid, b_out_ptr, b_out_node, b_pool_ptr, b_pool_rid,
         b_pool_cn, b_isend, b_esrc, b_support;
     DevBuf m_seqs, m_off, m_cols0, m_cols1, m_counts, m_moves, m_trace, m_out;
 
@@ -287,6 +287,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     jd.qcap = qcap;
     jd.tabA = (double*)b_tabA.ensure(sizeof(double) * (size_t)qcap * MAXS);
     jd.tabL = (double*)b_tabL.ensure(sizeof(double) * (size_t)std::min<long>(qcap, MAX_DRAWS) * 128);
+    jd.tabLf = (float*)b_tabLf.ensure(sizeof(float) * (size_t)std::min<long>(qcap, MAX_DRAWS) * 128);
     jd.qflag = (uint8_t*)b_qflag.ensure((size_t)qcap + 8);
     jd.qcode = (uint8_t*)b_qcode.ensure((size_t)qcap + 8);
     jd.qent = (int*)b_qent.ensure(sizeof(int) * (size_t)qcap);
@@ -369,7 +370,8 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     bool branching = false;
     std::vector<std::pair<int, int>> pending_copies;     // (src slot, dst slot) for the next launch
     double sampler_ms = 0;
-    long sampler_launches = 0, level_launches = 0, draws = 0, exact = 0, sampler_copies = 0;
+    long sampler_launches = 0, level_launches = 0, draws = 0, exact = 0, slow = 0, sampler_copies = 0, sampler_strains = 0, redo = 0;
+    unsigned long long chain_cycles = 0, chain_wall = 0;
 
     auto run_level = [&](int mode, int e0, int e1, int Q, int n_sweeps, bool do_update, const std::vector<HStrain>& sv,
                          bool has_dups, bool any_multi) {
@@ -405,7 +407,8 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
             sampler_ms += ms; sampler_launches++; sampler_copies += Q;
-            draws += (long)Rh->n_draws; exact += (long)Rh->n_exact;
+            draws += (long)Rh->n_draws; exact += (long)Rh->n_exact; slow += (long)Rh->n_slow; sampler_strains += S; redo += (long)Rh->n_redo;
+            chain_cycles += Rh->chain_cycles; chain_wall += Rh->chain_wall;
         }
     };
 
@@ -623,6 +626,11 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     job.stats.level_launches = level_launches;
     job.stats.draws = draws;
     job.stats.exact_draws = exact;
+    job.stats.slow_draws = slow;
+    job.stats.redo_blocks = redo;
+    job.stats.chain_cycles = (long)chain_cycles;
+    job.stats.chain_wall_ticks = (long)chain_wall;
+    job.stats.sampler_strains = sampler_strains;
 }
 
 void Worker::process(Job& job) {

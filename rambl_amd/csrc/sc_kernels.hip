@@ -19,6 +19,15 @@
 
 namespace sc {
 
+constexpr int LDS_TOTAL = 160 * 1024;
+constexpr int LDS_SMALL = 9 * 1024;            // per-strain scalars
+constexpr int LDS_BIG = LDS_TOTAL - LDS_SMALL;
+constexpr int LDS_REC = MAX_DRAWS + 64;
+constexpr int LDS_ROWS_FLOATS = (LDS_BIG - LDS_REC) / 4;
+static_assert(LDS_SMALL >= (int)(sizeof(double) * 3 * MAXS + sizeof(unsigned) * MAXS * KMAX + sizeof(int) * 3 * MAXS), "LDS_SMALL");
+static_assert(LDS_BIG >= (int)(sizeof(double) * MAXS * KK), "LDS_BIG");
+static_assert(LDS_REC % 4 == 0, "LDS_REC");
+
 // --------------------------------------------------------------------------
 // wave64 helpers
 template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
@@ -94,7 +103,11 @@ __global__ __launch_bounds__(256) void k_edge_support(const int* __restrict__ ou
 // forms it (NonparametricClustering.cpp:171-194 with libstdc++'s
 // discrete_distribution): executed by lane 0 of the sampling wave for the rare
 // draw whose uniform lies within the safety margin of a boundary.
-__device__ int exact_draw(const JobDev& job, const int* s_slot, const volatile double* s_a,
+struct SlowArgs {          // the few JobDev fields the rare tiers need, passed by value
+    const double* tabL; const uint8_t* qflag; const int* qent; const int* quid; const int* ent_rid;
+    const double* ll; long ll_stride; const uint8_t* has;
+};
+__device__ int exact_draw(const SlowArgs job, const int* s_slot, const volatile double* s_a,
                           volatile double* s_p, int S, int rid, int uid, double u) {
     double Z = 0;
     for (int s = 0; s < S; s++) Z += s_a[s];
@@ -124,35 +137,114 @@ __device__ int exact_draw(const JobDev& job, const int* s_slot, const volatile d
     return lo;
 }
 
-constexpr double DRAW_EPS = 1e-10;   // relative safety margin of the fast categorical draw
+constexpr double DRAW_EPS64 = 1e-10;  // margin (relative to the total weight) of the fp64 scan tier
+constexpr float DRAW_EPS32 = 1e-5f;   // margin of the fp32 scan tier (fp32 scan error <= ~6e-7 of the total)
 
-// The urn chain: NonparametricClustering.cpp:161-210 (and :796-829).  Runs on one
-// wavefront.  NPL strains per lane (strain index = lane*NPL + i).
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, BOUND));
+}
+__device__ __forceinline__ float wave_scan_incl_f32(float v) {
+    v += dpp_f32<0x111, 0xF, 0xF, true>(v);
+    v += dpp_f32<0x112, 0xF, 0xF, true>(v);
+    v += dpp_f32<0x114, 0xF, 0xF, true>(v);
+    v += dpp_f32<0x118, 0xF, 0xF, true>(v);
+    v += dpp_f32<0x142, 0xA, 0xF, false>(v);
+    v += dpp_f32<0x143, 0xC, 0xF, false>(v);
+    return v;
+}
+
+// Tier 2 and 3 of one draw: fp64 weights and scan with a 1e-10 margin; if the
+// uniform is still within the margin of a boundary (or the slot is flagged for
+// underflow), the literal evaluation.  Wave-uniform call.
 template <int NPL>
-__device__ void urn_chain(const JobDev& job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
-                          const int* s_slot, volatile double* s_a, volatile double* s_p, unsigned* s_cnt, int lane) {
-    const int S = P->S, Q = P->Q, n = P->n_sweeps;
+__device__ __noinline__ int slow_draw(const SlowArgs job, const int* s_slot, volatile double* s_a, volatile double* s_p,
+                                      double a0, double a1, int S, int q, int e0, double u, int lane) {
+    const double a[2] = {a0, a1};
     constexpr int SPAD = 64 * NPL;
-    double a[NPL];
+    double w[NPL], pair = 0;
 #pragma unroll
-    for (int i = 0; i < NPL; i++) { int s = lane * NPL + i; a[i] = s < S ? P->a0[s] : 0.0; }
-    unsigned long long n_exact = 0;
-    const long total = (long)n * Q;
-    // software prefetch of the weight rows, 4 draws ahead
-    constexpr int PF = 4;
-    double rowbuf[PF][NPL];
+    for (int i = 0; i < NPL; i++) { w[i] = a[i] * job.tabL[(long)q * SPAD + lane * NPL + i]; pair += w[i]; }
+    const double incl = wave_scan_incl(pair);
+    const double T = readlane_f64(incl, 63);
+    const double tgt = u * T;
+    const double lo = tgt - DRAW_EPS64 * T, hi = tgt + DRAW_EPS64 * T;
+    bool ok = (T > 0.0) && (T < 1.0e300) && !job.qflag[q];
+    int c;
+    if (NPL == 1) {
+        const unsigned long long mlo = __ballot(incl >= lo), mhi = __ballot(incl >= hi);
+        ok = ok && (mlo == mhi) && (mlo != 0ull);
+        c = ok ? (int)__builtin_ctzll(mlo) : 0;
+    } else {
+        const double E = wave_shr1(incl);
+        const double c0 = E + w[0], c1 = E + pair;
+        const unsigned long long m0lo = __ballot(c0 >= lo), m0hi = __ballot(c0 >= hi);
+        const unsigned long long m1lo = __ballot(c1 >= lo), m1hi = __ballot(c1 >= hi);
+        ok = ok && (m0lo == m0hi) && (m1lo == m1hi) && (m1lo != 0ull);
+        const int l1 = ok ? (int)__builtin_ctzll(m1lo) : 0;
+        c = 2 * l1 + (((m0lo >> l1) & 1ull) ? 0 : 1);
+    }
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < NPL; i++) { int s = lane * NPL + i; if (s < S) s_a[s] = a[i]; }
+        __builtin_amdgcn_wave_barrier();
+        int cc = 0;
+        if (lane == 0) cc = exact_draw(job, s_slot, s_a, s_p, S, job.ent_rid[e0 + job.qent[q]], job.quid[q], u);
+        c = __builtin_amdgcn_readfirstlane(cc);
+        __builtin_amdgcn_wave_barrier();
+        c |= 0x100;                                    // tell the caller the literal tier ran
+    }
+    return c;
+}
+
+// The urn chain: NonparametricClustering.cpp:161-210 (and :796-829).  One
+// wavefront; NPL strains per lane (strain index = lane*NPL + i).
+// Tier 1 per draw: fp32 weights a_s * L[q][s] (L = exp(loglik - max), staged in
+// LDS when it fits, ROWS_LDS), DPP prefix scan, two ballots around u*T.  The
+// chosen strain is recorded per draw (one byte) and histogrammed afterwards.
+template <int NPL, bool ROWS_LDS>
+__device__ void urn_chain(const JobDev& job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
+                          const int* s_slot, volatile double* s_a, volatile double* s_p, unsigned char* rec,
+                          const float* rows_lds, int lane) {
+    const int S = P->S, Q = P->Q, n = P->n_sweeps, e0 = P->e0;
+    constexpr int SPAD = 64 * NPL;
+    const SlowArgs sa{job.tabL, job.qflag, job.qent, job.quid, job.ent_rid, job.ll, job.ll_stride, job.has};
+    const double* Ustream = job.U;
+    const float* rows = ROWS_LDS ? rows_lds : job.tabLf;
+    const int stride = ROWS_LDS ? S : SPAD;
+    double a[NPL];
+    float af[NPL];
+    bool act[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; i++) {
+        const int s = lane * NPL + i;
+        act[i] = s < S;
+        a[i] = act[i] ? P->a0[s] : 0.0;
+        af[i] = (float)a[i];
+    }
+    unsigned long long n_exact = 0, n_slow = 0;
+    const int total = n * Q;
+    constexpr int PF = ROWS_LDS ? 2 : 8;                 // draws of row prefetch
+    float rowbuf[PF][NPL];
+    int qpf = 0;
 #pragma unroll
     for (int d = 0; d < PF; d++) {
-        int qq = d % Q;
 #pragma unroll
-        for (int i = 0; i < NPL; i++) rowbuf[d][i] = job.tabL[(long)qq * SPAD + lane * NPL + i];
+        for (int i = 0; i < NPL; i++) rowbuf[d][i] = act[i] ? rows[qpf * stride + lane * NPL + i] : 0.0f;
+        qpf = (qpf + 1 == Q) ? 0 : qpf + 1;
     }
-    int q = 0, qpf = PF % Q;
+    int q = 0;
     double ublk = 0;
-    for (long t = 0; t < total; t++) {
-        if ((t & 63) == 0) ublk = (t + lane < MAX_DRAWS) ? job.U[t + lane] : 0.0;
-        const double u = readlane_f64(ublk, (int)(t & 63));
-        double L[NPL];
+    float ublkf = 0;
+    unsigned crec = 0;
+    for (int t = 0; t < total; t++) {
+        const int tl = t & 63;
+        if (tl == 0) {
+            ublk = (t + lane < MAX_DRAWS) ? Ustream[t + lane] : 0.0;
+            ublkf = (float)ublk;
+        }
+        const float uf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublkf), tl));
+        float L[NPL];
 #pragma unroll
         for (int i = 0; i < NPL; i++) L[i] = rowbuf[0][i];
 #pragma unroll
@@ -160,51 +252,205 @@ __device__ void urn_chain(const JobDev& job, const LevelParams* __restrict__ P, 
 #pragma unroll
             for (int i = 0; i < NPL; i++) rowbuf[d][i] = rowbuf[d + 1][i];
 #pragma unroll
-        for (int i = 0; i < NPL; i++) rowbuf[PF - 1][i] = job.tabL[(long)qpf * SPAD + lane * NPL + i];
+        for (int i = 0; i < NPL; i++) rowbuf[PF - 1][i] = act[i] ? rows[qpf * stride + lane * NPL + i] : 0.0f;
         qpf = (qpf + 1 == Q) ? 0 : qpf + 1;
 
-        double w[NPL], pair = 0;
+        float w[NPL], pair = 0.0f;
 #pragma unroll
-        for (int i = 0; i < NPL; i++) { w[i] = a[i] * L[i]; pair += w[i]; }
-        const double incl = wave_scan_incl(pair);
-        const double T = readlane_f64(incl, 63);
-        const double tgt = u * T;
-        const double lo = tgt * (1.0 - DRAW_EPS), hi = tgt * (1.0 + DRAW_EPS);
+        for (int i = 0; i < NPL; i++) { w[i] = af[i] * L[i]; pair += w[i]; }
+        const float incl = wave_scan_incl_f32(pair);
+        const float T = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+        const float tgt = uf * T, mg = DRAW_EPS32 * T;
+        const float lo = tgt - mg, hi = tgt + mg;
         int c;
-        bool fast = (T > 0.0) && (T < 1.0e300) && !job.qflag[q];
+        bool fast = (T > 0.0f) && (T < 1.0e30f);         // a flagged slot has a NaN row: T is NaN
         if (NPL == 1) {
             const unsigned long long mlo = __ballot(incl >= lo), mhi = __ballot(incl >= hi);
             fast = fast && (mlo == mhi) && (mlo != 0ull);
-            c = fast ? (int)__builtin_ctzll(mlo) : 0;
+            c = (int)__builtin_ctzll(mlo | (1ull << 63));
         } else {
-            const double E = wave_shr1(incl);
-            const double c0 = E + w[0];
-            const double c1 = E + pair;
+            const float E = dpp_f32<0x138, 0xF, 0xF, true>(incl);   // wave_shr:1
+            const float c0 = E + w[0], c1 = E + pair;
             const unsigned long long m0lo = __ballot(c0 >= lo), m0hi = __ballot(c0 >= hi);
             const unsigned long long m1lo = __ballot(c1 >= lo), m1hi = __ballot(c1 >= hi);
             fast = fast && (m0lo == m0hi) && (m1lo == m1hi) && (m1lo != 0ull);
-            int l1 = fast ? (int)__builtin_ctzll(m1lo) : 0;
+            const int l1 = (int)__builtin_ctzll(m1lo | (1ull << 63));
             c = 2 * l1 + (((m0lo >> l1) & 1ull) ? 0 : 1);
         }
         if (!fast) {
-#pragma unroll
-            for (int i = 0; i < NPL; i++) { int s = lane * NPL + i; if (s < S) s_a[s] = a[i]; }
-            __builtin_amdgcn_wave_barrier();
-            int cc = 0;
-            if (lane == 0) cc = exact_draw(job, s_slot, s_a, s_p, S, job.ent_rid[P->e0 + job.qent[q]], job.quid[q], u);
-            c = __builtin_amdgcn_readfirstlane(cc);
-            __builtin_amdgcn_wave_barrier();
-            n_exact++;
+            const double u = readlane_f64(ublk, tl);
+            c = slow_draw<NPL>(sa, s_slot, s_a, s_p, a[0], NPL > 1 ? a[NPL - 1] : 0.0, S, q, e0, u, lane);
+            n_slow++;
+            n_exact += (c >> 8) & 1;
+            c &= 0xFF;
         }
 #pragma unroll
-        for (int i = 0; i < NPL; i++) if (lane * NPL + i == c) a[i] += 1.0;
-        const int code = job.qcode[q];
-        if (lane == 0 && code < KMAX) s_cnt[c * KMAX + code] += 1u;
+        for (int i = 0; i < NPL; i++) {
+            a[i] += (lane * NPL + i == c) ? 1.0 : 0.0;
+            af[i] = (float)a[i];
+        }
+        crec = (lane == tl) ? (unsigned)c : crec;
+        if (tl == 63) rec[t - 63 + lane] = (unsigned char)crec;
         q = (q + 1 == Q) ? 0 : q + 1;
     }
+    if (total & 63) { const int base = total & ~63; if (base + lane < total) rec[base + lane] = (unsigned char)crec; }
 #pragma unroll
     for (int i = 0; i < NPL; i++) { int s = lane * NPL + i; if (s < S) R->abund[s] = a[i]; }
-    if (lane == 0) { R->n_draws = (unsigned long long)total; R->n_exact = n_exact; }
+    if (lane == 0) { R->n_draws = (unsigned long long)total; R->n_exact = n_exact; R->n_slow = n_slow; }
+}
+
+// --------------------------------------------------------------------------
+// Block-speculative urn chain for S <= 64 (one strain per lane).
+//
+// The only loop-carried value of a draw is the per-lane count kf of draws already
+// assigned to the lane's strain: weight = (a0 + kf) * L[q][lane].  A block of 32
+// draws runs without any branch or scalar round trip on the dependent chain:
+//   fp32 DPP prefix scan (DEPTH steps) -> T = readlane -> the lane with
+//   excl < u*T <= incl adds 1 to its kf and sets its bit in a 32-draw history.
+// Each lane also tests |incl - u*T| against the safety margin (sticky flag).  At
+// the end of the block one ballot decides: no flag -> the 32 decisions equal the
+// reference's and the history is committed into per-(lane, read symbol) counters
+// with six popcounts; any flag (about 0.4 % of blocks) -> kf is restored and the
+// block is replayed draw by draw through the checked tiers (fp32 with branch, fp64
+// scan, literal evaluation).
+template <int DEPTH>
+__device__ __forceinline__ float scan_f32_depth(float v) {
+    v += dpp_f32<0x111, 0xF, 0xF, true>(v);
+    v += dpp_f32<0x112, 0xF, 0xF, true>(v);
+    v += dpp_f32<0x114, 0xF, 0xF, true>(v);
+    v += dpp_f32<0x118, 0xF, 0xF, true>(v);
+    if (DEPTH >= 5) v += dpp_f32<0x142, 0xA, 0xF, false>(v);
+    if (DEPTH >= 6) v += dpp_f32<0x143, 0xC, 0xF, false>(v);
+    return v;
+}
+
+template <int DEPTH, bool ROWS_LDS>
+__device__ void urn_chain_blocks(const JobDev& job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
+                                 const int* s_slot, volatile double* s_a, volatile double* s_p,
+                                 const float* rows_lds, const unsigned char* qcode_lds, int lane) {
+    const int S = P->S, Q = P->Q, n = P->n_sweeps, e0 = P->e0;
+    constexpr int TL = DEPTH == 4 ? 15 : (DEPTH == 5 ? 31 : 63);
+    constexpr int SPAD = 64;
+    constexpr int B = 32;
+    const SlowArgs sa{job.tabL, job.qflag, job.qent, job.quid, job.ent_rid, job.ll, job.ll_stride, job.has};
+    const double* Ustream = job.U;
+    const float* rows = ROWS_LDS ? rows_lds : job.tabLf;
+    const int stride = ROWS_LDS ? S : SPAD;
+    const bool act = lane < S;
+    const double a0 = act ? P->a0[lane] : 0.0;
+    const float a0f = (float)a0;
+    float kf = 0.0f;
+    unsigned cnt[KMAX];
+#pragma unroll
+    for (int b = 0; b < KMAX; b++) cnt[b] = 0;
+    unsigned long long n_exact = 0, n_slow = 0, n_redo = 0;
+    const int total = n * Q;
+    constexpr int PF = ROWS_LDS ? 2 : 8;
+    float rowbuf[PF];
+    int qpf = 0;
+#pragma unroll
+    for (int d = 0; d < PF; d++) {
+        rowbuf[d] = act ? rows[qpf * stride + lane] : 0.0f;
+        qpf = (qpf + 1 == Q) ? 0 : qpf + 1;
+    }
+    int q = 0;                      // slot of the next draw
+    double ublk = 0;
+    float ublkf = 0;
+    const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
+    for (int t0 = 0; t0 < total; t0 += B) {
+        const int nb = (total - t0 < B) ? (total - t0) : B;
+        if ((t0 & 63) == 0) {
+            ublk = (t0 + lane < MAX_DRAWS) ? Ustream[t0 + lane] : 0.0;
+            ublkf = (float)ublk;
+        }
+        // read symbol of draw i of the block, held by lane i
+        int qi = q + (lane & 31);
+        qi = qi >= Q ? qi % Q : qi;
+        const int mycode = qcode_lds[qi];
+        const float kf0 = kf;
+        const int q0 = q;
+        unsigned hist = 0;
+        float badf = 0.0f;
+        if (nb == B) {
+            for (int i = 0; i < B; i++) {
+                const float uf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublkf), (t0 & 32) + i));
+                const float L = rowbuf[0];
+#pragma unroll
+                for (int d = 0; d + 1 < PF; d++) rowbuf[d] = rowbuf[d + 1];
+                rowbuf[PF - 1] = act ? rows[qpf * stride + lane] : 0.0f;
+                qpf = (qpf + 1 == Q) ? 0 : qpf + 1;
+                const float w = (a0f + kf) * L;
+                const float incl = scan_f32_depth<DEPTH>(w);
+                // wave_shr:1; lane 0 keeps -1 so that it is selected when 0 <= u*T <= incl
+                const float excl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-1.0f), __float_as_int(incl), 0x138, 0xF, 0xF, false));
+                const float T = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), TL));
+                const float tgt = uf * T;
+                const float mg = DRAW_EPS32 * T + 1.0e-37f;
+                const float f1 = (incl >= tgt) ? 1.0f : 0.0f;
+                const float f0 = (excl >= tgt) ? 1.0f : 0.0f;
+                const float sel = f1 - f0;
+                kf += sel;
+                hist |= ((unsigned)sel) << i;
+                badf = !(fabsf(incl - tgt) >= mg) ? 1.0f : badf;
+            }
+            q = q0 + B; q = q >= Q ? q % Q : q;
+        }
+        const bool bad = (nb != B) || (__ballot(badf != 0.0f && lane <= TL) != 0ull);
+        if (!bad) {
+#pragma unroll
+            for (int b = 0; b < KMAX; b++) {
+                const unsigned mask = (unsigned)__ballot(mycode == b);
+                cnt[b] += __popc(hist & mask);
+            }
+        } else {
+            // replay the block through the checked tiers
+            n_redo++;
+            kf = kf0;
+            int qq = q0;
+            for (int i = 0; i < nb; i++) {
+                const int t = t0 + i;
+                const float uf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublkf), t & 63));
+                const float L = act ? rows[qq * stride + lane] : 0.0f;
+                const float w = (a0f + kf) * L;
+                const float incl = scan_f32_depth<DEPTH>(w);
+                const float T = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), TL));
+                const float tgt = uf * T, mg = DRAW_EPS32 * T + 1.0e-37f;
+                const unsigned long long live = (TL == 63) ? ~0ull : ((1ull << (TL + 1)) - 1ull);
+                const unsigned long long mlo = __ballot(incl >= tgt - mg) & live, mhi = __ballot(incl >= tgt + mg) & live;
+                int c;
+                if ((T > 0.0f) && (T < 1.0e30f) && (mlo == mhi) && (mlo != 0ull)) {
+                    c = (int)__builtin_ctzll(mlo);
+                } else {
+                    const double u = readlane_f64(ublk, t & 63);
+                    c = slow_draw<1>(sa, s_slot, s_a, s_p, a0 + (double)kf, 0.0, S, qq, e0, u, lane);
+                    n_slow++;
+                    n_exact += (c >> 8) & 1;
+                    c &= 0xFF;
+                }
+                const int code = qcode_lds[qq];
+                if (lane == c) {
+                    kf += 1.0f;
+#pragma unroll
+                    for (int b = 0; b < KMAX; b++) cnt[b] += (code == b) ? 1u : 0u;
+                }
+                qq = (qq + 1 == Q) ? 0 : qq + 1;
+            }
+            if (nb == B) {
+                // the speculative pass already advanced the row prefetch window; it stays valid
+            } else {
+                q = qq;
+            }
+        }
+    }
+    if (act) {
+        R->abund[lane] = a0 + (double)kf;
+#pragma unroll
+        for (int b = 0; b < KMAX; b++) R->cnt[lane * KMAX + b] = cnt[b];
+    }
+    if (lane == 0) {
+        R->n_draws = (unsigned long long)total; R->n_exact = n_exact; R->n_slow = n_slow; R->n_redo = n_redo;
+        R->chain_cycles = clock64() - clk0; R->chain_wall = wall_clock64() - wall0;     // shader clock / 100 MHz ticks
+    }
 }
 
 // --------------------------------------------------------------------------
@@ -212,14 +458,18 @@ __device__ void urn_chain(const JobDev& job, const LevelParams* __restrict__ P, 
 __global__ __launch_bounds__(1024) void k_level(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
                                                 int do_update) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    double* s_tab = reinterpret_cast<double*>(s_raw);            // [MAXS*KK] lpt, later the substitution histogram
-    double* s_a = s_tab + MAXS * KK;                             // [MAXS]
+    double* s_a = reinterpret_cast<double*>(s_raw);              // [MAXS]
     double* s_p = s_a + MAXS;                                    // [MAXS]
     double* s_logpri = s_p + MAXS;                               // [MAXS]
     unsigned* s_cnt = reinterpret_cast<unsigned*>(s_logpri + MAXS);   // [MAXS*KMAX]
     int* s_slot = reinterpret_cast<int*>(s_cnt + MAXS * KMAX);   // [MAXS]
     int* s_laboff = s_slot + MAXS;                               // [MAXS]
     int* s_lablen = s_laboff + MAXS;                             // [MAXS]
+    unsigned char* s_big = s_raw + LDS_SMALL;                    // LDS_BIG bytes, reused per phase:
+    double* s_tab = reinterpret_cast<double*>(s_big);            //   [MAXS*KK] lpt, later the substitution histogram
+    unsigned char* s_rec = s_big;                                //   sampler: chosen strain per draw [MAX_DRAWS+64] (two strains per lane)
+    unsigned char* s_qcode = s_big;                              //   sampler: read symbol per draw slot [Q] (one strain per lane)
+    float* s_rows = reinterpret_cast<float*>(s_big + LDS_REC);   //   sampler: fp32 weight rows [Q][S] when they fit
     const int tid = threadIdx.x, nt = blockDim.x;
     const int S = P->S, K = job.K, e0 = P->e0, Rn = P->e1 - P->e0;
     const long stride = job.ll_stride;
@@ -234,7 +484,7 @@ __global__ __launch_bounds__(1024) void k_level(JobDev job, const LevelParams* _
         __syncthreads();                       // a later copy may read this row
     }
     if (tid < MAXS * KMAX) s_cnt[tid] = 0;
-    if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; }
+    if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_redo = 0; R->chain_cycles = 0; R->chain_wall = 0; }
     __syncthreads();
 
     // ---- phase 1: read log-likelihood update, NonparametricClustering.cpp:343-391
@@ -387,6 +637,7 @@ __global__ __launch_bounds__(1024) void k_level(JobDev job, const LevelParams* _
     // ---- MODE_SAMPLE: np_bayes_clustering / read_assign
     if (P->n_sweeps <= 0 || S == 1) return;           // nothing to draw (host handles S == 1 and n == 0)
     const int SPAD = (S <= 64) ? 64 : 128;
+    const bool rows_lds = (long)Q * S <= LDS_ROWS_FLOATS;
     for (long idx = tid; idx < (long)S * Q; idx += nt) {
         const int s = (int)(idx / Q), q = (int)(idx % Q);
         const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
@@ -399,17 +650,49 @@ __global__ __launch_bounds__(1024) void k_level(JobDev job, const LevelParams* _
     for (int q = tid; q < Q; q += nt) {
         double m = -INFINITY;
         for (int s = 0; s < S; s++) m = fmax(m, job.tabA[(long)s * job.qcap + q]);
-        job.qflag[q] = (m >= -600.0) ? 0 : 1;             // also catches NaN / -inf
+        const bool flag = !(m >= -600.0);                 // underflow range of the reference's exp(); also NaN / -inf
+        job.qflag[q] = flag ? 1 : 0;
+        if (SPAD == 64) s_qcode[q] = job.qcode[q];
         double* Lr = job.tabL + (long)q * SPAD;
-        for (int s = 0; s < S; s++) Lr[s] = exp(job.tabA[(long)s * job.qcap + q] - m);
+        float* Lf = rows_lds ? (s_rows + (long)q * S) : (job.tabLf + (long)q * SPAD);
+        for (int s = 0; s < S; s++) {
+            const double v = exp(job.tabA[(long)s * job.qcap + q] - m);
+            Lr[s] = v;
+            Lf[s] = flag ? __int_as_float(0x7fc00000) : (float)v;
+        }
         for (int s = S; s < SPAD; s++) Lr[s] = 0.0;
+        if (!rows_lds) for (int s = S; s < SPAD; s++) Lf[s] = 0.0f;
     }
     __syncthreads();
     if (tid < 64) {
-        if (SPAD == 64) urn_chain<1>(job, P, R, s_slot, s_a, s_p, s_cnt, tid);
-        else urn_chain<2>(job, P, R, s_slot, s_a, s_p, s_cnt, tid);
-        __builtin_amdgcn_wave_barrier();
-        for (int i = tid; i < S * KMAX; i += 64) R->cnt[i] = s_cnt[i];
+        if (SPAD == 64) {
+            // stage the read symbols of the draw slots behind the rows
+            // (done by all threads below, before this wave starts)
+            if (S <= 16) {
+                if (rows_lds) urn_chain_blocks<4, true>(job, P, R, s_slot, s_a, s_p, s_rows, s_qcode, tid);
+                else urn_chain_blocks<4, false>(job, P, R, s_slot, s_a, s_p, s_rows, s_qcode, tid);
+            } else if (S <= 32) {
+                if (rows_lds) urn_chain_blocks<5, true>(job, P, R, s_slot, s_a, s_p, s_rows, s_qcode, tid);
+                else urn_chain_blocks<5, false>(job, P, R, s_slot, s_a, s_p, s_rows, s_qcode, tid);
+            } else {
+                if (rows_lds) urn_chain_blocks<6, true>(job, P, R, s_slot, s_a, s_p, s_rows, s_qcode, tid);
+                else urn_chain_blocks<6, false>(job, P, R, s_slot, s_a, s_p, s_rows, s_qcode, tid);
+            }
+        } else {
+            if (rows_lds) urn_chain<2, true>(job, P, R, s_slot, s_a, s_p, s_rec, s_rows, tid);
+            else urn_chain<2, false>(job, P, R, s_slot, s_a, s_p, s_rec, s_rows, tid);
+        }
+    }
+    __syncthreads();
+    // draws per (strain, read symbol): the substitution counts of :198-206
+    if (SPAD != 64) {
+        const int total = P->n_sweeps * Q;
+        for (int t = tid; t < total; t += nt) {
+            const int code = job.qcode[t % Q];
+            if (code < KMAX) atomicAdd(&s_cnt[(int)s_rec[t] * KMAX + code], 1u);
+        }
+        __syncthreads();
+        for (int i = tid; i < S * KMAX; i += nt) R->cnt[i] = s_cnt[i];
     }
 }
 
@@ -573,7 +856,7 @@ void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node
     hipLaunchKernelGGL(k_edge_support, dim3(blocks), dim3(256), 0, st, out_ptr, out_node, pool_ptr, pool_rid, pool_cn,
                        node_is_end, edge_src, n_edges, sorted, support);
 }
-constexpr size_t LEVEL_LDS = sizeof(double) * (MAXS * KK + 3 * MAXS) + sizeof(unsigned) * MAXS * KMAX + sizeof(int) * 3 * MAXS;
+constexpr size_t LEVEL_LDS = LDS_TOTAL;
 int init_kernels() {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEVEL_LDS);
 }
