@@ -1,0 +1,151 @@
+"""CPU: host-side pieces of the product path against the oracle -- Python ingest
+(rows a1-a4), the C++ graph builder (a5, a6, a9-a11; MSA callback = oracle), the
+libstdc++ sort port, the mt19937 stream, the CLI surface."""
+import ctypes
+import io
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import sc_testlib as T
+from rambl_amd import cli, ingest
+
+ROOT = T.ROOT
+
+
+def _dump_reads(args, d):
+    base = os.path.join(d, "dump")
+    T.run_oracle(args, d, graph=True, dump_reads=base)
+    out = []
+    i = 0
+    while os.path.exists("%s.%d" % (base, i)):
+        out.append(open("%s.%d" % (base, i)).read().splitlines())
+        i += 1
+    return out, base
+
+
+@pytest.mark.parametrize("seed", list(range(0, 12)))
+def test_ingest_matches_oracle(seed, tmp_path, oracle_bin):
+    d = str(tmp_path)
+    args = T.make_case(seed, d)
+    dumps, _ = _dump_reads(args, d)
+    pa = cli.parse_cmd_line(args)
+    regs = cli.load_regions(pa)
+    assert len(regs) == len(dumps)
+    for (w, r), lines in zip(regs, dumps):
+        assert lines[0].split("\t")[1:] == [w[0], str(w[1]), str(w[2])]
+        assert lines[1].split("\t")[1] == r.gene_seq
+        exp = [l.split("\t") for l in lines[2:]]
+        assert len(exp) == len(r)
+        for i, e in enumerate(exp):
+            got = [str(r.pos[i]), r.cigar[i], r.seq[i], str(r.copies[i]), ",".join(map(str, r.mates[i]))]
+            assert got == e[1:6]
+
+
+@pytest.fixture(scope="session")
+def graph_check_bin(oracle_bin, tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("native") / "graph_host_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", out, os.path.join(ROOT, "tests", "native", "graph_host_check.cpp"),
+                           os.path.join(ROOT, "rambl_amd", "csrc", "sc_graph.cpp"), "-L" + os.path.join(ROOT, "oracle"),
+                           "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    return out
+
+
+@pytest.mark.parametrize("seed", list(range(0, 16)))
+def test_host_graph_matches_oracle(seed, tmp_path, oracle_bin, graph_check_bin):
+    d = str(tmp_path)
+    args = T.make_case(seed, d)
+    base = os.path.join(d, "dump")
+    exp_g, _ = T.run_oracle(args, d, graph=True, dump_reads=base)
+    got = ""
+    i = 0
+    while os.path.exists("%s.%d" % (base, i)):
+        lines = open("%s.%d" % (base, i)).read().splitlines()
+        if len(lines) > 2:
+            p = subprocess.run([graph_check_bin, "%s.%d" % (base, i)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert p.returncode == 0, p.stderr.decode()
+            assert "unsupported ''" in p.stderr.decode()
+            got += p.stdout.decode()
+        i += 1
+    assert got == exp_g
+
+
+def test_sort_port_matches_libstdcxx(tmp_path, oracle_bin):
+    """oracle's std::sort port vs the real libstdc++ std::sort on keys full of ties."""
+    src = tmp_path / "s.cpp"
+    src.write_text(r'''
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+int main() { int n; while (scanf("%d", &n) == 1) { std::vector<double> k(n); for (auto& x : k) scanf("%lf", &x);
+  std::vector<int> p(n); for (int i = 0; i < n; i++) p[i] = i;
+  std::sort(p.begin(), p.end(), [&](int a, int b) { return k[a] > k[b]; });
+  for (int i = 0; i < n; i++) printf("%d ", p[i]); printf("\n"); } }
+''')
+    exe = str(tmp_path / "s")
+    subprocess.check_call(["g++", "-O1", "-o", exe, str(src)])
+    lib = T.oracle_lib()
+    rng = random.Random(3)
+    text, cases = [], []
+    for _ in range(300):
+        n = rng.choice([1, 2, 5, 16, 17, 18, 33, 80, 81, 200, 1000])
+        keys = [float(rng.randint(0, max(1, n // rng.choice([1, 2, 8])))) for _ in range(n)]
+        cases.append(keys)
+        text.append("%d %s" % (n, " ".join(map(repr, keys))))
+    out = subprocess.run([exe], input="\n".join(text).encode(), stdout=subprocess.PIPE).stdout.decode().splitlines()
+    for keys, line in zip(cases, out):
+        n = len(keys)
+        perm = (ctypes.c_int * n)()
+        lib.oracle_sort_desc_perm((ctypes.c_double * n)(*keys), n, perm)
+        assert list(perm) == [int(x) for x in line.split()]
+
+
+def test_mt19937_canonical_stream(oracle_bin):
+    lib = T.oracle_lib()
+    n = 3000
+    out = (ctypes.c_double * n)()
+    lib.oracle_mt_canonical(1234, n, out)
+    gen = ingest.MT19937(1234)
+    assert [gen.canonical() for _ in range(n)] == list(out)
+    # std::mt19937 known answer: the 10000th output of the default-seeded engine is 4123659995
+    g = ingest.MT19937(5489)
+    v = 0
+    for _ in range(10000):
+        v = g.next_u32()
+    assert v == 4123659995
+
+
+def test_cli_argv_forms():
+    pa = cli.parse_cmd_line(["-r", "g:1-10", "--window", "77", "-overlap", "5", "-e", "0.5", "-q", "7", "-D", "9",
+                             "-I", "3", "-l", "44", "-t", "0.25", "--diff-rate", "0.125", "-G", "--bogus", "a.fa", "b.bam", "c.bam"])
+    assert (pa.roi, pa.window_size, pa.overlap_size, pa.mapping_qual, pa.max_depth, pa.max_ins, pa.read_len) == \
+        ("g:1-10", 77, 5, 7, 9, 3, 44)
+    assert float(pa.error_rate) == 0.5 and float(pa.tau) == 0.25 and float(pa.diff_rate) == 0.125
+    assert pa.plot_graph and pa.gene_file == "a.fa" and pa.mapping_file == "c.bam"
+    assert float(cli.parse_cmd_line(["-t", "0.02"]).tau) == float(np.float32(0.02))
+    assert ingest.stoi("12abc") == 12
+    with pytest.raises(ValueError):
+        ingest.stoi("abc")
+    assert ingest.gene_roi_end_pos("g:1-9") == 9
+    with pytest.raises(ValueError):            # first '-' of the WHOLE roi (StrainCall.cpp:210-220): stoi("b:1-9") throws
+        ingest.gene_roi_end_pos("a-b:1-9")
+
+
+def test_cli_help_goes_to_stderr():
+    out, err = io.StringIO(), io.StringIO()
+    assert cli.main([], out=out, err=err) == 0
+    assert out.getvalue() == "" and err.getvalue().startswith("StrainCall marker_gene read_mapping")
+    out, err = io.StringIO(), io.StringIO()
+    assert cli.main(["-h", "x.fa", "y.sam"], out=out, err=err) == 0
+    assert "-G,--plot-graph    print graph" in err.getvalue()
+
+
+def test_crop_and_cigar_helpers():
+    assert ingest.parse_cigar("3S10M2I4D5=6X") == [("S", 3), ("M", 10), ("I", 2), ("D", 4), ("M", 5), ("M", 6)]
+    cig = ingest.parse_cigar("10M")
+    assert ingest.crop_read_within_window(5, 8, "ACGTACGTAC", "IIIIIIIIII", cig, 3, 12) == ("GTAC", "4M")
+    assert ingest.crop_read_within_window(1, 100, "ACGTACGTAC", "IIIIIIIIII", cig, 3, 12) == ("ACGTACGTAC", "10M")
+    assert ingest.max_insert_size("5M3I2M7I1M") == 7
