@@ -54,3 +54,56 @@ def test_config2_full_size_matches_reference_fasta(tmp_path):
     assert T.run_product(args) == got
     # domain property: the abundant contigs are the planted strains (generator truth), up to the window ends
     assert got.count(">") >= 3
+
+
+def _golden_cases():
+    import json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return sorted(json.load(open(os.path.join(gold, "index.json"))))
+
+
+@pytest.mark.parametrize("name", _golden_cases())
+def test_golden_reference_outputs(name, tmp_path):
+    """The HIP path against outputs of the REFERENCE itself (committed fixtures):
+    FASTA and graph dump bit-exact, per-level trace to 1e-9 (fp64 vs x87)."""
+    from test_oracle_golden import load_case
+    args, exp_fa, exp_g, exp_tr = load_case(name, str(tmp_path))
+    tf = os.path.join(str(tmp_path), "p.trace")
+    assert T.run_product(args, trace_file=tf) == exp_fa
+    assert T.run_product(args, graph=True) == exp_g
+    T.compare_traces(open(tf).read(), exp_tr)
+
+
+@pytest.mark.parametrize("seed", [1, 7, 9, 15])
+def test_edge_support_kernel(seed, tmp_path):
+    """k_edge_support (row a16) against the supports the -G dump prints."""
+    from rambl_amd import capi, cli
+    args = T.make_case(seed, str(tmp_path))
+    pa = cli.parse_cmd_line(args)
+    regs = cli.load_regions(pa)
+    params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate))
+    with capi.Context(0, 1) as ctx:
+        for window, reads in regs:
+            if len(reads) == 0:
+                continue
+            h = ctx.submit(reads, params)
+            res = ctx.wait(h, want_graph=True, release=False)
+            sup = ctx.edge_support(h)
+            ctx.lib.sc_roi_release(ctx.h, h)
+            edges = [l.split("\t") for l in res.graph.splitlines() if not l.startswith("#")]
+            assert [int(e[2]) for e in edges] == sup
+
+
+def test_regions_in_flight_are_independent(tmp_path):
+    """Several regions on separate streams give the same FASTA as one at a time."""
+    from rambl_amd import capi, cli, stage5
+    prepared, single = [], []
+    for seed in (0, 2, 4, 9):
+        d = os.path.join(str(tmp_path), "s%d" % seed)
+        args = T.make_case(seed, d)
+        pa = cli.parse_cmd_line(args)
+        prepared.append((pa, cli.load_regions(pa)))
+        single.append(T.run_product(args))
+    with capi.Context(0, 4) as ctx:
+        texts, _ = stage5.run_regions(ctx, prepared, streams=4)
+    assert texts == single
