@@ -121,6 +121,12 @@ def main():
         draws = sum(s["draws"] for s in all_stats)
         avg_ms = k_ms / max(k_n, 1)
         achieved = (ALG_BYTES_PER_READ * k_copies / max(k_n, 1)) / (avg_ms * 1e-3) if k_n else 0.0
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+        if os.path.exists(pmc) and world == 1:
+            # HBM bytes per SAMPLE launch from the committed rocprofv3 --pmc passes of this command
+            traffic = json.load(open(pmc)).get("sample_traffic_bytes_per_launch")
+            traffic_src = "profiles/r01/pmc_summary.json (separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled)"
         line = {
             "metric": "reads/sec into POA (150bp, ~1.5k-node graph)", "value": total_reads / dt, "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -129,7 +135,8 @@ def main():
                                    "rambl.py options (-q 0 -D 800 -I 13 -l 70 -t 0.02 -d 0.02 -w 5000)" % (a.reads, a.glen, a.strains),
                        "regions_per_gpu": 1, "parallelism": "region-sharded x%d, FASTA gather over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": "k_level (SAMPLE: urn sampler)", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_READ * k_copies / max(k_n, 1),
                          "avg_launch_ms": avg_ms, "launches_per_step": k_n / max(a.steps, 1),
                          "draws_per_s_per_wavefront": draws / (k_ms * 1e-3) if k_ms else 0.0},
             "breakdown_ms_per_step": {"graph_host": sum(s["graph_ms"] for s in all_stats) / a.steps,

@@ -37,6 +37,7 @@ void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node
                          const int* pool_cn, const uint8_t* node_is_end, const int* edge_src, int n_edges, int sorted,
                          int* support);
 void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int do_update);
+void launch_chain(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int S, int Q);
 void launch_msa(hipStream_t st, const MsaDev& d);
 int init_kernels();
 
@@ -286,8 +287,8 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     jd.isnew = (uint8_t*)b_isnew.ensure((size_t)max_level_entries + 8);
     jd.qcap = qcap;
     jd.tabA = (double*)b_tabA.ensure(sizeof(double) * (size_t)qcap * MAXS);
-    jd.tabL = (double*)b_tabL.ensure(sizeof(double) * (size_t)std::min<long>(qcap, MAX_DRAWS) * 128);
-    jd.tabLf = (float*)b_tabLf.ensure(sizeof(float) * (size_t)std::min<long>(qcap, MAX_DRAWS) * 128);
+    jd.qmax = (double*)b_tabL.ensure(sizeof(double) * (size_t)qcap);
+    jd.tabLf = (float*)b_tabLf.ensure(sizeof(float) * (size_t)(std::min<long>(qcap, MAX_DRAWS) + 4) * 128);
     jd.qflag = (uint8_t*)b_qflag.ensure((size_t)qcap + 8);
     jd.qcode = (uint8_t*)b_qcode.ensure((size_t)qcap + 8);
     jd.qent = (int*)b_qent.ensure(sizeof(int) * (size_t)qcap);
@@ -373,6 +374,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     long sampler_launches = 0, level_launches = 0, draws = 0, exact = 0, slow = 0, sampler_copies = 0, sampler_strains = 0, redo = 0;
     unsigned long long chain_cycles = 0, chain_wall = 0;
 
+    FILE* level_log = getenv("SC_LEVEL_LOG") ? fopen(getenv("SC_LEVEL_LOG"), "a") : nullptr;   // diagnostics only
     auto run_level = [&](int mode, int e0, int e1, int Q, int n_sweeps, bool do_update, const std::vector<HStrain>& sv,
                          bool has_dups, bool any_multi) {
         LevelParams& P = *Ph;
@@ -396,16 +398,22 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         }
         const size_t bytes = offsetof(LevelParams, lpt) + sizeof(double) * (size_t)S * KK;
         HIPCHK(hipMemcpyAsync(Pd, Ph, bytes, hipMemcpyHostToDevice, st));
-        const bool timed = (mode == MODE_SAMPLE);
-        if (timed) HIPCHK(hipEventRecord(ev0, st));
+        const bool timed = (mode == MODE_SAMPLE) && S > 1 && n_sweeps > 0;
         launch_level(st, jd, Pd, Rd, do_update ? 1 : 0);
-        if (timed) HIPCHK(hipEventRecord(ev1, st));
+        if (timed) {
+            HIPCHK(hipEventRecord(ev0, st));
+            launch_chain(st, jd, Pd, Rd, S, Q);
+            HIPCHK(hipEventRecord(ev1, st));
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
         level_launches++;
         if (timed) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+            if (level_log) fprintf(level_log, "S %d Q %d n %d ms %.4f redo %llu slow %llu cyc %llu redocyc %llu\n", S, Q, n_sweeps, ms,
+                                   (unsigned long long)Rh->n_redo, (unsigned long long)Rh->n_slow,
+                                   (unsigned long long)Rh->chain_cycles, (unsigned long long)Rh->redo_cycles);
             sampler_ms += ms; sampler_launches++; sampler_copies += Q;
             draws += (long)Rh->n_draws; exact += (long)Rh->n_exact; slow += (long)Rh->n_slow; sampler_strains += S; redo += (long)Rh->n_redo;
             chain_cycles += Rh->chain_cycles; chain_wall += Rh->chain_wall;
@@ -620,6 +628,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             job.abund.push_back(s.abundance);
         }
     }
+    if (level_log) fclose(level_log);
     job.stats.sampler_kernel_ms = sampler_ms;
     job.stats.sampler_launches = sampler_launches;
     job.stats.sampler_read_copies = sampler_copies;
@@ -703,7 +712,7 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
     sc_ctx* h = new sc_ctx();
     Ctx* ctx = &h->c;
     ctx->device = device;
-    std::vector<double> u = uniform_stream(1234u, MAX_DRAWS + 64);
+    std::vector<double> u = uniform_stream(1234u, MAX_DRAWS + 2048);   // padded: the chain stages windows of 1024
     if (hipMalloc((void**)&ctx->dU, sizeof(double) * u.size()) != hipSuccess ||
         hipMemcpy(ctx->dU, u.data(), sizeof(double) * u.size(), hipMemcpyHostToDevice) != hipSuccess) {
         delete h;

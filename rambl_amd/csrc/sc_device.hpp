@@ -37,7 +37,7 @@ struct JobDev {
     // scratch
     uint8_t* isnew;              // [max entries per level]
     double* tabA;                // [MAXS][qcap]  LLq / P  (strain-major)
-    double* tabL;                // [qcap][SPAD]  sampler weights, fp64 (draw-major)
+    double* qmax;                // [qcap] max over strains of the draw slot's log-likelihood
     float* tabLf;                // [qcap][SPAD]  sampler weights, fp32, when they do not fit in LDS
     uint8_t* qflag;              // [qcap] exact-path flag per draw slot
     uint8_t* qcode;              // [qcap] read-label symbol code of a draw slot (0xFF: not a single symbol)
@@ -72,7 +72,9 @@ struct LevelResult {
     unsigned cnt[MAXS * KMAX];   // SAMPLE: draws per (strain, read symbol)
     unsigned long long n_draws;
     unsigned long long n_slow;   // draws that needed the fp64 scan tier
-    unsigned long long n_redo;   // 32-draw blocks replayed through the checked tiers
+    unsigned long long n_redo;   // 16-draw blocks replayed one draw at a time
+    unsigned long long n_careful;   // draws that went through the per-draw checked path
+    unsigned long long redo_cycles;  // shader cycles spent replaying flagged blocks
     unsigned long long chain_cycles, chain_wall;   // shader cycles / 100 MHz ticks spent in the urn chain
     unsigned long long n_exact;  // draws resolved by the literal fp64 path
     int error;

@@ -754,7 +754,7 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
         sub.clear();
     }
     f.n_levels = level;
-    if (f.K > 8 && f.unsupported.empty()) f.unsupported = "more than 8 distinct symbols in node/read labels";
+    if (f.K > 7 && f.unsupported.empty()) f.unsupported = "more than 7 distinct symbols in node/read labels";
 }
 
 }  // namespace sc

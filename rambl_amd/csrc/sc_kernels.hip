@@ -19,11 +19,15 @@
 
 namespace sc {
 
-constexpr int LDS_TOTAL = 160 * 1024;
+#define SC_GLOBAL __attribute__((address_space(1)))
+#define SC_LDS __attribute__((address_space(3)))
+
+constexpr int LDS_TOTAL = 160 * 1024 - 256;   // dynamic part; the rest covers small static __shared__ variables
 constexpr int LDS_SMALL = 9 * 1024;            // per-strain scalars
 constexpr int LDS_BIG = LDS_TOTAL - LDS_SMALL;
 constexpr int LDS_REC = MAX_DRAWS + 64;
-constexpr int LDS_ROWS_FLOATS = (LDS_BIG - LDS_REC) / 4;
+constexpr int LDS_ROWS_FLOATS = (LDS_BIG - LDS_REC) / 4;    // two-strains-per-lane path (S > 64)
+constexpr int LDS_UBUF = 4096;                            // 1024 staged uniforms (S <= 64 path)
 static_assert(LDS_SMALL >= (int)(sizeof(double) * 3 * MAXS + sizeof(unsigned) * MAXS * KMAX + sizeof(int) * 3 * MAXS), "LDS_SMALL");
 static_assert(LDS_BIG >= (int)(sizeof(double) * MAXS * KK), "LDS_BIG");
 static_assert(LDS_REC % 4 == 0, "LDS_REC");
@@ -104,8 +108,8 @@ __global__ __launch_bounds__(256) void k_edge_support(const int* __restrict__ ou
 // discrete_distribution): executed by lane 0 of the sampling wave for the rare
 // draw whose uniform lies within the safety margin of a boundary.
 struct SlowArgs {          // the few JobDev fields the rare tiers need, passed by value
-    const double* tabL; const uint8_t* qflag; const int* qent; const int* quid; const int* ent_rid;
-    const double* ll; long ll_stride; const uint8_t* has;
+    const double* tabA; const double* qmax; long qcap; const uint8_t* qflag; const int* qent; const int* quid;
+    const int* ent_rid; const double* ll; long ll_stride; const uint8_t* has;
 };
 __device__ int exact_draw(const SlowArgs job, const int* s_slot, const volatile double* s_a,
                           volatile double* s_p, int S, int rid, int uid, double u) {
@@ -161,10 +165,15 @@ template <int NPL>
 __device__ __noinline__ int slow_draw(const SlowArgs job, const int* s_slot, volatile double* s_a, volatile double* s_p,
                                       double a0, double a1, int S, int q, int e0, double u, int lane) {
     const double a[2] = {a0, a1};
-    constexpr int SPAD = 64 * NPL;
     double w[NPL], pair = 0;
+    const double m = job.qmax[q];
 #pragma unroll
-    for (int i = 0; i < NPL; i++) { w[i] = a[i] * job.tabL[(long)q * SPAD + lane * NPL + i]; pair += w[i]; }
+    for (int i = 0; i < NPL; i++) {
+        const int s = lane * NPL + i;
+        // fp64 weight a_s * exp(loglik - max), rebuilt from the strain-major table on demand
+        w[i] = (s < S) ? a[i] * exp(job.tabA[(long)s * job.qcap + q] - m) : 0.0;
+        pair += w[i];
+    }
     const double incl = wave_scan_incl(pair);
     const double T = readlane_f64(incl, 63);
     const double tgt = u * T;
@@ -208,7 +217,7 @@ __device__ void urn_chain(const JobDev& job, const LevelParams* __restrict__ P, 
                           const float* rows_lds, int lane) {
     const int S = P->S, Q = P->Q, n = P->n_sweeps, e0 = P->e0;
     constexpr int SPAD = 64 * NPL;
-    const SlowArgs sa{job.tabL, job.qflag, job.qent, job.quid, job.ent_rid, job.ll, job.ll_stride, job.has};
+    const SlowArgs sa{job.tabA, job.qmax, job.qcap, job.qflag, job.qent, job.quid, job.ent_rid, job.ll, job.ll_stride, job.has};
     const double* Ustream = job.U;
     const float* rows = ROWS_LDS ? rows_lds : job.tabLf;
     const int stride = ROWS_LDS ? S : SPAD;
@@ -300,162 +309,367 @@ __device__ void urn_chain(const JobDev& job, const LevelParams* __restrict__ P, 
 }
 
 // --------------------------------------------------------------------------
-// Block-speculative urn chain for S <= 64 (one strain per lane).
+// Grouped urn chain for S <= 64: four draws per iteration.
 //
-// The only loop-carried value of a draw is the per-lane count kf of draws already
-// assigned to the lane's strain: weight = (a0 + kf) * L[q][lane].  A block of 32
-// draws runs without any branch or scalar round trip on the dependent chain:
-//   fp32 DPP prefix scan (DEPTH steps) -> T = readlane -> the lane with
-//   excl < u*T <= incl adds 1 to its kf and sets its bit in a 32-draw history.
-// Each lane also tests |incl - u*T| against the safety margin (sticky flag).  At
-// the end of the block one ballot decides: no flag -> the 32 decisions equal the
-// reference's and the history is committed into per-(lane, read symbol) counters
-// with six popcounts; any flag (about 0.4 % of blocks) -> kf is restored and the
-// block is replayed draw by draw through the checked tiers (fp32 with branch, fp64
-// scan, literal evaluation).
-template <int DEPTH>
-__device__ __forceinline__ float scan_f32_depth(float v) {
+// The wave is split into its four DPP rows; row r works on draw t+r of a batch of
+// four, with the 16 lanes of a row holding NPL = 1, 2 or 4 consecutive strains
+// each (strain = col*NPL + i).  Every row carries a replica of the per-strain
+// counts k.  All four draws of a batch are decided from the counts at the START
+// of the batch; draw r is accepted only if no boundary lies within
+// (1e-5*T + r) of u*T -- r bounds the shift the <= r earlier draws of the batch
+// can cause, because every weight factor L is <= 1.  The chain per batch is:
+// in-lane prefix -> 4-step row scan (row_shr) -> T by row_newbcast:15 -> compares
+// -> sum of the selections over the rows (v_permlane16_swap, v_permlane32_swap)
+// -> k += sum.  Eight batches form a block; one ballot per block tests the sticky
+// per-lane flags.  A flagged block restores k and replays its 32 draws one at a
+// time (row 0 only) through the checked tiers.
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rows_sum4(float x) {
+    uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float y = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    uint2v r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+}
+__device__ __forceinline__ float row_scan16(float v) {
     v += dpp_f32<0x111, 0xF, 0xF, true>(v);
     v += dpp_f32<0x112, 0xF, 0xF, true>(v);
     v += dpp_f32<0x114, 0xF, 0xF, true>(v);
     v += dpp_f32<0x118, 0xF, 0xF, true>(v);
-    if (DEPTH >= 5) v += dpp_f32<0x142, 0xA, 0xF, false>(v);
-    if (DEPTH >= 6) v += dpp_f32<0x143, 0xC, 0xF, false>(v);
     return v;
 }
 
-template <int DEPTH, bool ROWS_LDS>
-__device__ void urn_chain_blocks(const JobDev& job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
-                                 const int* s_slot, volatile double* s_a, volatile double* s_p,
-                                 const float* rows_lds, const unsigned char* qcode_lds, int lane) {
-    const int S = P->S, Q = P->Q, n = P->n_sweeps, e0 = P->e0;
-    constexpr int TL = DEPTH == 4 ? 15 : (DEPTH == 5 ? 31 : 63);
-    constexpr int SPAD = 64;
-    constexpr int B = 32;
-    const SlowArgs sa{job.tabL, job.qflag, job.qent, job.quid, job.ent_rid, job.ll, job.ll_stride, job.has};
-    const double* Ustream = job.U;
-    const float* rows = ROWS_LDS ? rows_lds : job.tabLf;
-    const int stride = ROWS_LDS ? S : SPAD;
-    const bool act = lane < S;
-    const double a0 = act ? P->a0[lane] : 0.0;
-    const float a0f = (float)a0;
-    float kf = 0.0f;
-    unsigned cnt[KMAX];
-#pragma unroll
-    for (int b = 0; b < KMAX; b++) cnt[b] = 0;
-    unsigned long long n_exact = 0, n_slow = 0, n_redo = 0;
-    const int total = n * Q;
-    constexpr int PF = ROWS_LDS ? 2 : 8;
-    float rowbuf[PF];
-    int qpf = 0;
-#pragma unroll
-    for (int d = 0; d < PF; d++) {
-        rowbuf[d] = act ? rows[qpf * stride + lane] : 0.0f;
-        qpf = (qpf + 1 == Q) ? 0 : qpf + 1;
-    }
-    int q = 0;                      // slot of the next draw
-    double ublk = 0;
-    float ublkf = 0;
-    const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
-    for (int t0 = 0; t0 < total; t0 += B) {
-        const int nb = (total - t0 < B) ? (total - t0) : B;
-        if ((t0 & 63) == 0) {
-            ublk = (t0 + lane < MAX_DRAWS) ? Ustream[t0 + lane] : 0.0;
-            ublkf = (float)ublk;
-        }
-        // read symbol of draw i of the block, held by lane i
-        int qi = q + (lane & 31);
-        qi = qi >= Q ? qi % Q : qi;
-        const int mycode = qcode_lds[qi];
-        const float kf0 = kf;
-        const int q0 = q;
-        unsigned hist = 0;
-        float badf = 0.0f;
-        if (nb == B) {
-            for (int i = 0; i < B; i++) {
-                const float uf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublkf), (t0 & 32) + i));
-                const float L = rowbuf[0];
-#pragma unroll
-                for (int d = 0; d + 1 < PF; d++) rowbuf[d] = rowbuf[d + 1];
-                rowbuf[PF - 1] = act ? rows[qpf * stride + lane] : 0.0f;
-                qpf = (qpf + 1 == Q) ? 0 : qpf + 1;
-                const float w = (a0f + kf) * L;
-                const float incl = scan_f32_depth<DEPTH>(w);
-                // wave_shr:1; lane 0 keeps -1 so that it is selected when 0 <= u*T <= incl
-                const float excl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-1.0f), __float_as_int(incl), 0x138, 0xF, 0xF, false));
-                const float T = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), TL));
-                const float tgt = uf * T;
-                const float mg = DRAW_EPS32 * T + 1.0e-37f;
-                const float f1 = (incl >= tgt) ? 1.0f : 0.0f;
-                const float f0 = (excl >= tgt) ? 1.0f : 0.0f;
-                const float sel = f1 - f0;
-                kf += sel;
-                hist |= ((unsigned)sel) << i;
-                badf = !(fabsf(incl - tgt) >= mg) ? 1.0f : badf;
+// Tier 2 (sequential fp64 with a 1e-10 margin) and tier 3 (literal) for one draw,
+// run by lane 0; s_a holds the current urn weights a_s.
+__device__ __noinline__ int slow_draw_seq(const SlowArgs job, const int* s_slot, const volatile double* s_a,
+                                          volatile double* s_p, int S, int q, int e0, double u, int* tier3) {
+    *tier3 = 0;
+    if (!job.qflag[q]) {
+        const double m = job.qmax[q];
+        double T = 0;
+        for (int s = 0; s < S; s++) { T += s_a[s] * exp(job.tabA[(long)s * job.qcap + q] - m); s_p[s] = T; }
+        if (T > 0.0 && T < 1.0e300) {
+            const double tgt = u * T, mg = DRAW_EPS64 * T;
+            int c = -1;
+            bool ok = true;
+            for (int s = 0; s < S; s++) {
+                const double cum = s_p[s];
+                if (fabs(cum - tgt) < mg) ok = false;
+                if (c < 0 && cum >= tgt) c = s;
             }
-            q = q0 + B; q = q >= Q ? q % Q : q;
+            if (!(tgt >= mg)) ok = false;
+            if (ok && c >= 0) return c;
         }
-        const bool bad = (nb != B) || (__ballot(badf != 0.0f && lane <= TL) != 0ull);
-        if (!bad) {
+    }
+    *tier3 = 1;
+    return exact_draw(job, s_slot, s_a, s_p, S, job.ent_rid[e0 + job.qent[q]], job.quid[q], u);
+}
+
+template <int NPL, bool ROWS_LDS>
+__device__ __forceinline__ void urn_chain_g4(const JobDev& job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
+                             const int* s_slot, volatile double* s_a, volatile double* s_p, unsigned* s_cnt,
+                             const float* rows_lds, const unsigned char* qcode_lds, float* ubuf, int any_flag, int lane) {
+    // Table layout expected from k_chain: rows [Q + 3][stride] (slots 0..2 repeated after the last,
+    // then zeros), qcode [Q + 3] (same), so that a batch starting at slot q < Q never wraps.
+    const int S = P->S, Q = P->Q, n = P->n_sweeps, e0 = P->e0;
+    const int row = lane >> 4, col = lane & 15;
+    constexpr int BB = 4;                                  // batches per block (16 draws)
+    constexpr int UB = 1024;                               // uniforms staged in LDS at a time
+    constexpr float BIG = 1.0e30f;
+    const SlowArgs sa{job.tabA, job.qmax, job.qcap, job.qflag, job.qent, job.quid, job.ent_rid, job.ll, job.ll_stride, job.has};
+    const SC_GLOBAL double* Ustream = (const SC_GLOBAL double*)job.U;
+    const SC_GLOBAL float* rows_g = (const SC_GLOBAL float*)job.tabLf;
+    const int stride = ROWS_LDS ? S : 64;
+    auto ld_row = [&](int idx) __attribute__((always_inline)) -> float { return ROWS_LDS ? rows_lds[idx] : rows_g[idx]; };
+    bool act[NPL];
+    double a0[NPL];
+    float a0f[NPL], kf[NPL];
+    unsigned cnt[NPL][KMAX];
 #pragma unroll
-            for (int b = 0; b < KMAX; b++) {
-                const unsigned mask = (unsigned)__ballot(mycode == b);
-                cnt[b] += __popc(hist & mask);
+    for (int i = 0; i < NPL; i++) {
+        const int s = col * NPL + i;
+        act[i] = s < S;
+        a0[i] = act[i] ? P->a0[s] : 0.0;
+        a0f[i] = (float)a0[i];
+        kf[i] = 0.0f;
+#pragma unroll
+        for (int b = 0; b < KMAX; b++) cnt[i][b] = 0;
+    }
+    unsigned long long n_exact = 0, n_slow = 0, n_redo = 0, n_careful = 0, redo_cycles = 0;
+    const int total = n * Q;
+    const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
+    const float mg_add = (float)row + 1.0e-37f;            // draw r of a batch tolerates r earlier increments
+    const int lane_row_off = row * stride + col * NPL;     // + q*stride = this lane's weights of draw slot q+row
+
+    // ---- level C: one draw at a time on row 0 through the checked tiers; count <= 64
+    auto careful_draws = [&](int t_begin, int count, int q_begin) __attribute__((always_inline)) {
+        int ql = q_begin + lane;
+        ql = ql >= Q ? ql % Q : ql;
+        const double ublk = (lane < count) ? Ustream[t_begin + lane] : 0.0;
+        const int cblk = qcode_lds[ql];
+        int qq = q_begin;
+        for (int d = 0; d < count; d++) {
+            const double u = readlane_f64(ublk, d);
+            const float uf = (float)u;
+            const int code = __builtin_amdgcn_readlane(cblk, d) >> 2;      // staged as 4*min(symbol, KMAX-1)
+            float pre[NPL];
+            float tot = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NPL; i++) {
+                const float L = (act[i] && row == 0) ? ld_row(qq * stride + col * NPL + i) : 0.0f;
+                tot += (a0f[i] + kf[i]) * L;
+                pre[i] = tot;
+            }
+            const float incl = row_scan16(tot);
+            const float base = dpp_f32<0x111, 0xF, 0xF, true>(incl);
+            const float T = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 15));
+            const float tgt = uf * T, mg = DRAW_EPS32 * T + 1.0e-37f;
+            bool near = !(fabsf(base - tgt) >= mg);
+            int csel = -1;
+            float prev = (col == 0) ? -1.0f : base;
+#pragma unroll
+            for (int i = 0; i < NPL; i++) {
+                const float cum = (i == NPL - 1) ? incl : base + pre[i];
+                near = near || !(fabsf(cum - tgt) >= mg);
+                if (cum >= tgt && !(prev >= tgt)) csel = col * NPL + i;
+                prev = cum;
+            }
+            const unsigned long long rowmask = 0xFFFFull;
+            const bool unsafe = !(T > 0.0f) || !(T < 1.0e30f) || ((__ballot(near) & rowmask) != 0ull);
+            const unsigned long long hit = __ballot(csel >= 0) & rowmask;
+            int c;
+            if (!unsafe && hit != 0ull) {
+                c = __builtin_amdgcn_readlane(csel, (int)__builtin_ctzll(hit));
+            } else {
+                if (row == 0) {
+#pragma unroll
+                    for (int i = 0; i < NPL; i++) { const int s = col * NPL + i; if (s < S) s_a[s] = a0[i] + (double)kf[i]; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                int cc = 0, t3 = 0;
+                if (lane == 0) cc = slow_draw_seq(sa, s_slot, s_a, s_p, S, qq, e0, u, &t3);
+                c = __builtin_amdgcn_readfirstlane(cc);
+                n_exact += (unsigned long long)__builtin_amdgcn_readfirstlane(t3);
+                __builtin_amdgcn_wave_barrier();
+                n_slow++;
+            }
+#pragma unroll
+            for (int i = 0; i < NPL; i++) {
+                const bool mine = (col * NPL + i == c);
+                kf[i] += mine ? 1.0f : 0.0f;                 // every row keeps its replica in step
+                if (row == 0 && mine) {
+#pragma unroll
+                    for (int b = 0; b < KMAX; b++) cnt[i][b] += (code == b) ? 1u : 0u;
+                }
+            }
+            qq = (qq + 1 == Q) ? 0 : qq + 1;
+        }
+        n_careful += count;
+    };
+
+    // ---- level B: replay of a flagged block, one draw per iteration, same branch-free body as a
+    // batch (every row computes the SAME draw, so the replicas stay in step without an exchange);
+    // one test at the end; still flagged -> level C.  count <= 64.
+    auto replay_draws = [&](int t_begin, int count, int q_begin) __attribute__((always_inline)) {
+        float kf1[NPL];
+        unsigned pk[NPL], pk2[NPL];                          // 4-bit fields: even / odd draws (<= 8 each)
+#pragma unroll
+        for (int i = 0; i < NPL; i++) { kf1[i] = kf[i]; pk[i] = 0; pk2[i] = 0; }
+        int ql = q_begin + lane;
+        ql = ql >= Q ? ql % Q : ql;
+        const float ublkf = (lane < count) ? (float)Ustream[t_begin + lane] : 0.0f;
+        const int cblk = qcode_lds[ql];
+        float slack = 1.0e30f;
+        int qq = q_begin;
+        const int lo = col * NPL;
+        for (int d = 0; d < count; d++) {
+            const float uf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublkf), d));
+            const unsigned sh = (unsigned)__builtin_amdgcn_readlane(cblk, d);
+            float pre[NPL], tot = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NPL; i++) { tot += (a0f[i] + kf[i]) * ld_row(qq * stride + lo + i); pre[i] = tot; }
+            const float incl = row_scan16(tot);
+            const float base = dpp_f32<0x111, 0xF, 0xF, true>(incl);
+            const float T = dpp_f32<0x15F, 0xF, 0xF, true>(incl);
+            const float tgt = uf * T;
+            const float mg = fmaf(DRAW_EPS32, T, 1.0e-37f);
+            float dprev = base - tgt;
+            float fprev = __builtin_amdgcn_fmed3f(dprev * BIG, 0.0f, 1.0f);
+            float dmin = fabsf(dprev);
+#pragma unroll
+            for (int i = 0; i < NPL; i++) {
+                const float cum = (i == NPL - 1) ? incl : base + pre[i];
+                const float dd = cum - tgt;
+                const float f = __builtin_amdgcn_fmed3f(dd * BIG, 0.0f, 1.0f);
+                dmin = fminf(dmin, fabsf(dd));
+                const float sel = f - fprev;
+                fprev = f;
+                kf[i] += sel;
+                if (d & 1) pk2[i] += ((unsigned)sel) << sh; else pk[i] += ((unsigned)sel) << sh;
+            }
+            slack = fminf(slack, dmin - mg);
+            qq = (qq + 1 == Q) ? 0 : qq + 1;
+        }
+        if (__ballot(!(slack >= 0.0f)) == 0ull) {
+            if (row == 0) {
+#pragma unroll
+                for (int i = 0; i < NPL; i++)
+#pragma unroll
+                    for (int b = 0; b < KMAX - 1; b++) cnt[i][b] += ((pk[i] >> (4 * b)) & 15u) + ((pk2[i] >> (4 * b)) & 15u);
             }
         } else {
-            // replay the block through the checked tiers
-            n_redo++;
-            kf = kf0;
-            int qq = q0;
-            for (int i = 0; i < nb; i++) {
-                const int t = t0 + i;
-                const float uf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublkf), t & 63));
-                const float L = act ? rows[qq * stride + lane] : 0.0f;
-                const float w = (a0f + kf) * L;
-                const float incl = scan_f32_depth<DEPTH>(w);
-                const float T = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), TL));
-                const float tgt = uf * T, mg = DRAW_EPS32 * T + 1.0e-37f;
-                const unsigned long long live = (TL == 63) ? ~0ull : ((1ull << (TL + 1)) - 1ull);
-                const unsigned long long mlo = __ballot(incl >= tgt - mg) & live, mhi = __ballot(incl >= tgt + mg) & live;
-                int c;
-                if ((T > 0.0f) && (T < 1.0e30f) && (mlo == mhi) && (mlo != 0ull)) {
-                    c = (int)__builtin_ctzll(mlo);
-                } else {
-                    const double u = readlane_f64(ublk, t & 63);
-                    c = slow_draw<1>(sa, s_slot, s_a, s_p, a0 + (double)kf, 0.0, S, qq, e0, u, lane);
-                    n_slow++;
-                    n_exact += (c >> 8) & 1;
-                    c &= 0xFF;
-                }
-                const int code = qcode_lds[qq];
-                if (lane == c) {
-                    kf += 1.0f;
 #pragma unroll
-                    for (int b = 0; b < KMAX; b++) cnt[b] += (code == b) ? 1u : 0u;
-                }
-                qq = (qq + 1 == Q) ? 0 : qq + 1;
-            }
-            if (nb == B) {
-                // the speculative pass already advanced the row prefetch window; it stays valid
-            } else {
-                q = qq;
-            }
+            for (int i = 0; i < NPL; i++) kf[i] = kf1[i];
+            careful_draws(t_begin, count, q_begin);
         }
-    }
-    if (act) {
-        R->abund[lane] = a0 + (double)kf;
+    };
+
+    // staging of the uniform stream: UB values at a time as fp32 in LDS
+    auto refill_u = [&](int base_t) __attribute__((always_inline)) {
+        double v[UB / 64];
 #pragma unroll
-        for (int b = 0; b < KMAX; b++) R->cnt[lane * KMAX + b] = cnt[b];
+        for (int k = 0; k < UB / 64; k++) v[k] = Ustream[base_t + k * 64 + lane];     // the stream is padded by UB entries
+#pragma unroll
+        for (int k = 0; k < UB / 64; k++) ubuf[k * 64 + lane] = (float)v[k];
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    const int full = (any_flag || Q < 4 * BB) ? 0 : total / (4 * BB);   // speculative blocks
+    int t = 0, q = 0;
+    // operands of the NEXT batch (software pipeline, one batch ahead); qn/tn are wave-uniform
+    float Ln[NPL];
+    float ufn = 0.0f;
+    unsigned shn = 0;
+    int qn = 0, tn = 0;
+    auto prefetch = [&]() __attribute__((always_inline)) {
+        const int ro = qn * stride + lane_row_off;
+#pragma unroll
+        for (int i = 0; i < NPL; i++) Ln[i] = ld_row(ro + i);
+        shn = qcode_lds[qn + row];
+        ufn = ubuf[(tn & (UB - 1)) + row];
+    };
+    if (full > 0) { refill_u(0); prefetch(); }
+    unsigned pkacc[NPL];                                     // committed history, unpacked every 3 blocks
+#pragma unroll
+    for (int i = 0; i < NPL; i++) pkacc[i] = 0;
+    int pending = 0;
+#pragma unroll 1
+    for (int blk = 0; blk < full; blk++) {
+        float kf0[NPL];
+        unsigned pk[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; i++) { kf0[i] = kf[i]; pk[i] = 0; }
+        float slack = 1.0e30f;                               // min over the block of (distance to a boundary - margin)
+#pragma unroll 1
+        for (int b = 0; b < BB; b++) {
+            float L[NPL];
+#pragma unroll
+            for (int i = 0; i < NPL; i++) L[i] = Ln[i];
+            const unsigned sh = shn;                         // 4*min(symbol, KMAX-1) of this row's draw
+            const float uf = ufn;
+            // advance to the next batch and issue its loads now
+            qn += 4; qn -= (qn >= Q) ? Q : 0;
+            tn += 4;
+            if (b == BB - 1 && (tn & (UB - 1)) == 0) refill_u(tn);    // next batch opens a new window of uniforms
+            prefetch();
+
+            float pre[NPL], tot = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NPL; i++) { tot += (a0f[i] + kf[i]) * L[i]; pre[i] = tot; }
+            const float incl = row_scan16(tot);
+            const float base = dpp_f32<0x111, 0xF, 0xF, true>(incl);            // previous lane of the row, 0 for col 0
+            const float T = dpp_f32<0x15F, 0xF, 0xF, true>(incl);               // row_newbcast:15
+            const float tgt = uf * T;
+            const float mg = fmaf(DRAW_EPS32, T, mg_add);
+            // f(x) = 1 if x >= tgt else 0 without compares: clamp((x - tgt) * BIG) to [0, 1]
+            float dprev = base - tgt;
+            float fprev = __builtin_amdgcn_fmed3f(dprev * BIG, 0.0f, 1.0f);
+            float dmin = fabsf(dprev);
+            unsigned word = 0;
+#pragma unroll
+            for (int i = 0; i < NPL; i++) {
+                const float cum = (i == NPL - 1) ? incl : base + pre[i];
+                const float d = cum - tgt;
+                const float f = __builtin_amdgcn_fmed3f(d * BIG, 0.0f, 1.0f);
+                dmin = fminf(dmin, fabsf(d));
+                const float sel = f - fprev;
+                fprev = f;
+                if (NPL == 1) {
+                    kf[0] += rows_sum4(sel);
+                    pk[0] += ((unsigned)sel) << sh;
+                } else {
+                    word = __builtin_amdgcn_cvt_pk_u8_f32(sel, i, word);
+                }
+            }
+            if (NPL > 1) {
+                uint2v r1 = __builtin_amdgcn_permlane16_swap(word, word, false, false);
+                const unsigned y = r1[0] + r1[1];
+                uint2v r2 = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+                const unsigned wsum = r2[0] + r2[1];
+#pragma unroll
+                for (int i = 0; i < NPL; i++) {
+                    kf[i] += (float)((wsum >> (8 * i)) & 0xFFu);
+                    pk[i] += ((word >> (8 * i)) & 0xFFu) << sh;
+                }
+            }
+            slack = fminf(slack, dmin - mg);
+        }
+        if (__ballot(!(slack >= 0.0f)) == 0ull) {
+#pragma unroll
+            for (int i = 0; i < NPL; i++) pkacc[i] += pk[i];                    // fields <= 4 per block
+            if (++pending == 3) {
+                pending = 0;
+#pragma unroll
+                for (int i = 0; i < NPL; i++) {
+#pragma unroll
+                    for (int b = 0; b < KMAX - 1; b++) cnt[i][b] += (pkacc[i] >> (4 * b)) & 15u;
+                    pkacc[i] = 0;
+                }
+            }
+        } else {
+            n_redo++;
+#pragma unroll
+            for (int i = 0; i < NPL; i++) kf[i] = kf0[i];
+            const unsigned long long r0 = clock64();
+            replay_draws(t, 4 * BB, q);
+            redo_cycles += clock64() - r0;
+        }
+        t += 4 * BB;
+        q += 4 * BB;
+        q -= (q >= Q) ? Q : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; i++)
+#pragma unroll
+        for (int b = 0; b < KMAX - 1; b++) cnt[i][b] += (pkacc[i] >> (4 * b)) & 15u;
+    q = (int)((long)t % Q);
+    while (t < total) {                                      // tail (and everything, if a slot is flagged)
+        const int count = (total - t < 64) ? (total - t) : 64;
+        careful_draws(t, count, q);
+        t += count;
+        q += count;
+        q = q >= Q ? q % Q : q;
+    }
+
+    // results: counts of all rows are summed through LDS
+#pragma unroll
+    for (int i = 0; i < NPL; i++) {
+        const int s = col * NPL + i;
+        if (s < S) {
+            if (row == 0) R->abund[s] = a0[i] + (double)kf[i];
+#pragma unroll
+            for (int b = 0; b < KMAX; b++) if (cnt[i][b]) atomicAdd(&s_cnt[s * KMAX + b], cnt[i][b]);
+        }
     }
     if (lane == 0) {
         R->n_draws = (unsigned long long)total; R->n_exact = n_exact; R->n_slow = n_slow; R->n_redo = n_redo;
-        R->chain_cycles = clock64() - clk0; R->chain_wall = wall_clock64() - wall0;     // shader clock / 100 MHz ticks
+        R->n_careful = n_careful;
+        R->chain_cycles = clock64() - clk0; R->chain_wall = wall_clock64() - wall0; R->redo_cycles = redo_cycles;
     }
 }
 
 // --------------------------------------------------------------------------
 // One level of the walk for one region.  Single workgroup.
-__global__ __launch_bounds__(1024) void k_level(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
+__global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
                                                 int do_update) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_a = reinterpret_cast<double*>(s_raw);              // [MAXS]
@@ -467,9 +681,6 @@ __global__ __launch_bounds__(1024) void k_level(JobDev job, const LevelParams* _
     int* s_lablen = s_laboff + MAXS;                             // [MAXS]
     unsigned char* s_big = s_raw + LDS_SMALL;                    // LDS_BIG bytes, reused per phase:
     double* s_tab = reinterpret_cast<double*>(s_big);            //   [MAXS*KK] lpt, later the substitution histogram
-    unsigned char* s_rec = s_big;                                //   sampler: chosen strain per draw [MAX_DRAWS+64] (two strains per lane)
-    unsigned char* s_qcode = s_big;                              //   sampler: read symbol per draw slot [Q] (one strain per lane)
-    float* s_rows = reinterpret_cast<float*>(s_big + LDS_REC);   //   sampler: fp32 weight rows [Q][S] when they fit
     const int tid = threadIdx.x, nt = blockDim.x;
     const int S = P->S, K = job.K, e0 = P->e0, Rn = P->e1 - P->e0;
     const long stride = job.ll_stride;
@@ -483,7 +694,7 @@ __global__ __launch_bounds__(1024) void k_level(JobDev job, const LevelParams* _
         for (int i = tid; i < n2; i += nt) dst[i] = src[i];
         __syncthreads();                       // a later copy may read this row
     }
-    if (tid < MAXS * KMAX) s_cnt[tid] = 0;
+    for (int i = tid; i < MAXS * KMAX; i += nt) s_cnt[i] = 0;
     if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_redo = 0; R->chain_cycles = 0; R->chain_wall = 0; }
     __syncthreads();
 
@@ -634,10 +845,8 @@ __global__ __launch_bounds__(1024) void k_level(JobDev job, const LevelParams* _
         return;
     }
 
-    // ---- MODE_SAMPLE: np_bayes_clustering / read_assign
+    // ---- MODE_SAMPLE: the per-slot log-likelihood table; k_chain draws from it
     if (P->n_sweeps <= 0 || S == 1) return;           // nothing to draw (host handles S == 1 and n == 0)
-    const int SPAD = (S <= 64) ? 64 : 128;
-    const bool rows_lds = (long)Q * S <= LDS_ROWS_FLOATS;
     for (long idx = tid; idx < (long)S * Q; idx += nt) {
         const int s = (int)(idx / Q), q = (int)(idx % Q);
         const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
@@ -646,54 +855,74 @@ __global__ __launch_bounds__(1024) void k_level(JobDev job, const LevelParams* _
         if (uid >= 0 && job.has[uid]) x += row[uid];
         job.tabA[(long)s * job.qcap + q] = x;
     }
+}
+
+// --------------------------------------------------------------------------
+// a14 / a18: the urn sampler of one level, np_bayes_clustering
+// (NonparametricClustering.cpp:128-244) and read_assign (:776-836).  One
+// workgroup: all threads turn the log-likelihood table into weight rows
+// L[q][s] = exp(ll - max_s ll) (fp32, in LDS when they fit), then one wavefront
+// runs the chain.  VARIANT: 1, 2, 4 = strains per lane of the grouped chain
+// (S <= 16, 32, 64); 0 = two strains per lane over 64 lanes (S <= 128).
+template <int VARIANT, bool ROWS_LDS>
+__global__ __launch_bounds__(256) void k_chain(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    double* s_a = reinterpret_cast<double*>(s_raw);              // [MAXS]
+    double* s_p = s_a + MAXS;                                    // [MAXS]
+    unsigned* s_cnt = reinterpret_cast<unsigned*>(s_p + MAXS);   // [MAXS*KMAX]
+    int* s_slot = reinterpret_cast<int*>(s_cnt + MAXS * KMAX);   // [MAXS]
+    unsigned char* s_big = s_raw + LDS_SMALL;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int S = P->S, Q = P->Q;
+    constexpr int SPAD = (VARIANT == 0) ? 128 : 64;
+    // VARIANT != 0: [read symbols: Q bytes, rounded][uniform window 4 KB][fp32 rows]; VARIANT 0: [record][rows]
+    const int qpad = (Q + 3 + 15) & ~15;
+    unsigned char* s_qcode = s_big;
+    unsigned char* s_rec = s_big;
+    float* s_ubuf = reinterpret_cast<float*>(s_big + qpad);
+    float* s_rows = (VARIANT == 0) ? reinterpret_cast<float*>(s_big + LDS_REC) : reinterpret_cast<float*>(s_big + qpad + LDS_UBUF);
+    __shared__ int s_anyflag;
+    for (int i = tid; i < MAXS * KMAX; i += nt) s_cnt[i] = 0;
+    if (tid < S) s_slot[tid] = P->slot[tid];
+    if (tid == 0) s_anyflag = 0;
     __syncthreads();
-    for (int q = tid; q < Q; q += nt) {
+    if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_redo = 0; R->chain_cycles = 0; R->chain_wall = 0; }
+    constexpr int WRAP = (VARIANT == 0) ? 0 : 3;     // slots 0..2 are repeated after the last one (grouped chain)
+    for (int qx = tid; qx < Q + WRAP; qx += nt) {
+        const int q = qx < Q ? qx : (qx - Q) % Q;
         double m = -INFINITY;
         for (int s = 0; s < S; s++) m = fmax(m, job.tabA[(long)s * job.qcap + q]);
         const bool flag = !(m >= -600.0);                 // underflow range of the reference's exp(); also NaN / -inf
-        job.qflag[q] = flag ? 1 : 0;
-        if (SPAD == 64) s_qcode[q] = job.qcode[q];
-        double* Lr = job.tabL + (long)q * SPAD;
-        float* Lf = rows_lds ? (s_rows + (long)q * S) : (job.tabLf + (long)q * SPAD);
+        if (qx < Q) {
+            job.qflag[q] = flag ? 1 : 0;
+            job.qmax[q] = m;
+            if (flag) atomicOr(&s_anyflag, 1);
+        }
+        if (VARIANT != 0) { const int c0 = job.qcode[q]; s_qcode[qx] = (unsigned char)(4 * (c0 < KMAX - 1 ? c0 : KMAX - 1)); }
+        float* Lf = ROWS_LDS ? (s_rows + (long)qx * S) : (job.tabLf + (long)qx * SPAD);
         for (int s = 0; s < S; s++) {
             const double v = exp(job.tabA[(long)s * job.qcap + q] - m);
-            Lr[s] = v;
-            Lf[s] = flag ? __int_as_float(0x7fc00000) : (float)v;
+            Lf[s] = flag ? __int_as_float(0x7fc00000) : (float)v;   // a NaN row sends every draw of the slot to the literal tier
         }
-        for (int s = S; s < SPAD; s++) Lr[s] = 0.0;
-        if (!rows_lds) for (int s = S; s < SPAD; s++) Lf[s] = 0.0f;
+        if (!ROWS_LDS) for (int s = S; s < SPAD; s++) Lf[s] = 0.0f;
     }
+    if (ROWS_LDS && VARIANT != 0) for (int i = tid; i < 64; i += nt) s_rows[(long)(Q + WRAP) * S + i] = 0.0f;   // read by lanes past S
     __syncthreads();
     if (tid < 64) {
-        if (SPAD == 64) {
-            // stage the read symbols of the draw slots behind the rows
-            // (done by all threads below, before this wave starts)
-            if (S <= 16) {
-                if (rows_lds) urn_chain_blocks<4, true>(job, P, R, s_slot, s_a, s_p, s_rows, s_qcode, tid);
-                else urn_chain_blocks<4, false>(job, P, R, s_slot, s_a, s_p, s_rows, s_qcode, tid);
-            } else if (S <= 32) {
-                if (rows_lds) urn_chain_blocks<5, true>(job, P, R, s_slot, s_a, s_p, s_rows, s_qcode, tid);
-                else urn_chain_blocks<5, false>(job, P, R, s_slot, s_a, s_p, s_rows, s_qcode, tid);
-            } else {
-                if (rows_lds) urn_chain_blocks<6, true>(job, P, R, s_slot, s_a, s_p, s_rows, s_qcode, tid);
-                else urn_chain_blocks<6, false>(job, P, R, s_slot, s_a, s_p, s_rows, s_qcode, tid);
-            }
-        } else {
-            if (rows_lds) urn_chain<2, true>(job, P, R, s_slot, s_a, s_p, s_rec, s_rows, tid);
-            else urn_chain<2, false>(job, P, R, s_slot, s_a, s_p, s_rec, s_rows, tid);
-        }
+        if (VARIANT == 0) urn_chain<2, ROWS_LDS>(job, P, R, s_slot, s_a, s_p, s_rec, s_rows, tid);
+        else urn_chain_g4<(VARIANT == 0 ? 1 : VARIANT), ROWS_LDS>(job, P, R, s_slot, s_a, s_p, s_cnt, s_rows, s_qcode, s_ubuf, s_anyflag, tid);
     }
     __syncthreads();
     // draws per (strain, read symbol): the substitution counts of :198-206
-    if (SPAD != 64) {
+    if (VARIANT == 0) {
         const int total = P->n_sweeps * Q;
         for (int t = tid; t < total; t += nt) {
             const int code = job.qcode[t % Q];
             if (code < KMAX) atomicAdd(&s_cnt[(int)s_rec[t] * KMAX + code], 1u);
         }
         __syncthreads();
-        for (int i = tid; i < S * KMAX; i += nt) R->cnt[i] = s_cnt[i];
     }
+    for (int i = tid; i < S * KMAX; i += nt) R->cnt[i] = s_cnt[i];
 }
 
 // --------------------------------------------------------------------------
@@ -856,12 +1085,36 @@ void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node
     hipLaunchKernelGGL(k_edge_support, dim3(blocks), dim3(256), 0, st, out_ptr, out_node, pool_ptr, pool_rid, pool_cn,
                        node_is_end, edge_src, n_edges, sorted, support);
 }
-constexpr size_t LEVEL_LDS = LDS_TOTAL;
+constexpr size_t LEVEL_LDS = LDS_SMALL + sizeof(double) * MAXS * KK;
+constexpr size_t CHAIN_LDS = LDS_TOTAL;
+template <int V, bool L> static int set_chain_attr() {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain<V, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
+}
 int init_kernels() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEVEL_LDS);
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEVEL_LDS);
+    rc |= set_chain_attr<0, true>(); rc |= set_chain_attr<0, false>();
+    rc |= set_chain_attr<1, true>(); rc |= set_chain_attr<1, false>();
+    rc |= set_chain_attr<2, true>(); rc |= set_chain_attr<2, false>();
+    rc |= set_chain_attr<4, true>(); rc |= set_chain_attr<4, false>();
+    return rc;
 }
 void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int do_update) {
-    hipLaunchKernelGGL(k_level, dim3(1), dim3(1024), LEVEL_LDS, st, job, P, R, do_update);
+    hipLaunchKernelGGL(k_level, dim3(1), dim3(512), LEVEL_LDS, st, job, P, R, do_update);
+}
+// S, Q of the level decide the chain variant and whether the fp32 rows fit in LDS.
+void launch_chain(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int S, int Q) {
+    const int qpad = (Q + 3 + 15) & ~15;
+    const int variant = S <= 16 ? 1 : (S <= 32 ? 2 : (S <= 64 ? 4 : 0));
+    const long cap = variant == 0 ? LDS_ROWS_FLOATS : (LDS_BIG - qpad - LDS_UBUF) / 4 - 64;
+    const bool lds = cap > 0 && (variant == 0 ? (long)Q * S : (long)(Q + 3) * S) <= cap;
+#define SC_CHAIN(V, L) hipLaunchKernelGGL((k_chain<V, L>), dim3(1), dim3(256), CHAIN_LDS, st, job, P, R)
+    switch (variant) {
+        case 1: if (lds) SC_CHAIN(1, true); else SC_CHAIN(1, false); break;
+        case 2: if (lds) SC_CHAIN(2, true); else SC_CHAIN(2, false); break;
+        case 4: if (lds) SC_CHAIN(4, true); else SC_CHAIN(4, false); break;
+        default: if (lds) SC_CHAIN(0, true); else SC_CHAIN(0, false); break;
+    }
+#undef SC_CHAIN
 }
 void launch_msa(hipStream_t st, const MsaDev& d) { hipLaunchKernelGGL(k_msa, dim3(1), dim3(256), 0, st, d); }
 
