@@ -134,7 +134,7 @@ def main():
             "config": {"workload": "configs[1]: %d x 150bp reads vs one %dbp gene, %d strains, seed 21(+rank), "
                                    "rambl.py options (-q 0 -D 800 -I 13 -l 70 -t 0.02 -d 0.02 -w 5000)" % (a.reads, a.glen, a.strains),
                        "regions_per_gpu": 1, "parallelism": "region-sharded x%d, FASTA gather over RCCL" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_level (SAMPLE: urn sampler)", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "sc::k_chain<V,L> (urn sampler of one level)", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_READ * k_copies / max(k_n, 1),
                          "avg_launch_ms": avg_ms, "launches_per_step": k_n / max(a.steps, 1),
