@@ -59,8 +59,13 @@ def main():
     ap.add_argument("--strains", type=int, default=3)
     ap.add_argument("--sample-roi", default="700-860")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--regions", type=int, default=1, help="regions per GPU and step (1 = BASELINE configs[1]; >1 = configs[2]-style batch)")
+    ap.add_argument("--streams", type=int, default=0, help="regions in flight per GPU (default: min(regions, 16))")
     a = ap.parse_args()
 
+    streams = a.streams if a.streams > 0 else min(a.regions, 16)
+    if streams > 4:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(streams, 24)))   # before HIP is initialised
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,21 +78,23 @@ def main():
     dev = torch.device("cuda", local)
 
     from rambl_amd import capi, cli, stage5, synth
-    seed = 21 + rank
     d = tempfile.mkdtemp(prefix="scbench_%d_" % rank)
-    fasta, sam, gene = synth.config2(d, seed=seed, n_reads=a.reads, glen=a.glen, n_strains=a.strains)
-    roi = "%s:1-%d" % (gene["name"], a.glen)
-    pa = cli.parse_cmd_line(stage5.straincall_argv(roi, fasta, sam))
-    regions = cli.load_regions(pa)                       # host ingest, outside the timed region
-    params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate))
-    ctx = capi.Context(local, 1)
+    prepared = []
+    for k in range(a.regions):
+        seed = 21 + rank * a.regions + k
+        gene = synth.make_gene(seed, glen=a.glen, n_strains=a.strains, n_reads=a.reads, name="gene%d" % seed)
+        fasta, sam = synth.write_dataset(os.path.join(d, "r%d" % k), [gene])
+        roi = "%s:1-%d" % (gene["name"], a.glen)
+        pa = cli.parse_cmd_line(stage5.straincall_argv(roi, fasta, sam))
+        prepared.append((pa, cli.load_regions(pa)))      # host ingest, outside the timed region
+    pa, regions = prepared[0]
+    fasta, sam = pa.gene_file, pa.mapping_file
+    gene = {"name": "gene%d" % (21 + rank * a.regions)}
+    params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate), want_timing=True)
+    ctx = capi.Context(local, streams)
 
     def step():
-        texts, stats = [], []
-        for window, reads in regions:
-            res = ctx.run(reads, params)
-            texts.append(cli.format_fasta(window, res, pa.tau))
-            stats.append(res.stats)
+        texts, stats = stage5.run_regions(ctx, prepared, streams, params)
         full = stage5.gather_fasta(["".join(texts)], [rank], world, dist if world > 1 else None, dev)
         return full, stats
 
@@ -114,7 +121,7 @@ def main():
     ctx.close()
 
     if rank == 0:
-        total_reads = a.reads * a.steps * world
+        total_reads = a.reads * a.regions * a.steps * world
         k_ms = sum(s["sampler_kernel_ms"] for s in all_stats)
         k_n = sum(s["sampler_launches"] for s in all_stats)
         k_copies = sum(s["sampler_read_copies"] for s in all_stats)
@@ -133,7 +140,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]: %d x 150bp reads vs one %dbp gene, %d strains, seed 21(+rank), "
                                    "rambl.py options (-q 0 -D 800 -I 13 -l 70 -t 0.02 -d 0.02 -w 5000)" % (a.reads, a.glen, a.strains),
-                       "regions_per_gpu": 1, "parallelism": "region-sharded x%d, FASTA gather over RCCL" % world},
+                       "regions_per_gpu": a.regions, "regions_in_flight_per_gpu": streams,
+                       "parallelism": "region-sharded x%d, FASTA gather over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": "sc::k_chain<V,L> (urn sampler of one level)", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_READ * k_copies / max(k_n, 1),
@@ -151,7 +159,7 @@ def main():
                                       "avg_candidates_per_sampler_launch": sum(s["sampler_strains"] for s in all_stats) / max(k_n, 1)},
             "contigs": fasta_out.count(">") if fasta_out else 0,
         }
-        if not a.no_cpu:
+        if not a.no_cpu and a.regions == 1:
             cb, cargs = cpu_baseline(d, fasta, sam, "%s:%s" % (gene["name"], a.sample_roi))
             ref_fa = cb.pop("fasta")
             # the same sample on the GPU, for a like-for-like ratio and a parity check of the sample

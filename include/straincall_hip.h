@@ -53,6 +53,7 @@ typedef struct sc_params {
     int max_candidates;    /* 80 */
     int graph_only;        /* -G: build + dump the graph, no clustering */
     int want_trace;        /* keep the per-level strain/abundance trace */
+    int want_timing;       /* time every sampler launch with HIP events on the region's stream (sc_stats) */
 } sc_params;
 
 typedef struct sc_stats {

@@ -398,25 +398,28 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         }
         const size_t bytes = offsetof(LevelParams, lpt) + sizeof(double) * (size_t)S * KK;
         HIPCHK(hipMemcpyAsync(Pd, Ph, bytes, hipMemcpyHostToDevice, st));
-        const bool timed = (mode == MODE_SAMPLE) && S > 1 && n_sweeps > 0;
+        const bool chain = (mode == MODE_SAMPLE) && S > 1 && n_sweeps > 0;
+        const bool timed = chain && pa.want_timing;
         launch_level(st, jd, Pd, Rd, do_update ? 1 : 0);
-        if (timed) {
-            HIPCHK(hipEventRecord(ev0, st));
+        if (chain) {
+            if (timed) HIPCHK(hipEventRecord(ev0, st));
             launch_chain(st, jd, Pd, Rd, S, Q);
-            HIPCHK(hipEventRecord(ev1, st));
+            if (timed) HIPCHK(hipEventRecord(ev1, st));
         }
-        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
         level_launches++;
+        if (chain) {
+            sampler_launches++; sampler_copies += Q;
+            draws += (long)Rh->n_draws; exact += (long)Rh->n_exact; slow += (long)Rh->n_slow; sampler_strains += S; redo += (long)Rh->n_redo;
+            chain_cycles += Rh->chain_cycles; chain_wall += Rh->chain_wall;
+        }
         if (timed) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
             if (level_log) fprintf(level_log, "S %d Q %d n %d ms %.4f redo %llu slow %llu cyc %llu redocyc %llu\n", S, Q, n_sweeps, ms,
                                    (unsigned long long)Rh->n_redo, (unsigned long long)Rh->n_slow,
                                    (unsigned long long)Rh->chain_cycles, (unsigned long long)Rh->redo_cycles);
-            sampler_ms += ms; sampler_launches++; sampler_copies += Q;
-            draws += (long)Rh->n_draws; exact += (long)Rh->n_exact; slow += (long)Rh->n_slow; sampler_strains += S; redo += (long)Rh->n_redo;
-            chain_cycles += Rh->chain_cycles; chain_wall += Rh->chain_wall;
+            sampler_ms += ms;
         }
     };
 
@@ -702,6 +705,10 @@ extern "C" {
 int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
     if (!out) return SC_ERR_ARG;
     *out = nullptr;
+    if (stream_count > 4 && !getenv("GPU_MAX_HW_QUEUES")) {
+        // one hardware queue per region in flight; only effective if HIP is not initialised yet
+        setenv("GPU_MAX_HW_QUEUES", std::to_string(stream_count > 24 ? 24 : stream_count).c_str(), 0);
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SC_ERR_NO_DEVICE;
     hipDeviceProp_t prop;

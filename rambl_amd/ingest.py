@@ -196,13 +196,7 @@ def window_adjust(aln, mq, gn, p0, p1, z, L):
     Q = p1 + z
     if Q > L:
         Q = L
-    info = {}
-    for line in aln.mpileup(mq, "%s:%d-%d" % (gn, P, Q)):
-        f = line.split()
-        f5 = f[4] if len(f) > 4 else ""
-        has_ins = "+" in f5
-        has_del = ("-" in f5) or ("*" in f5)
-        info[stoi(f[1])] = (has_ins, has_del)
+    info = aln.pileup_flags(mq, "%s:%d-%d" % (gn, P, Q))
     if not info:
         raise RuntimeError("no pileup for %s:%d-%d: the reference dereferences an empty map here" % (gn, p0, p1))
     keys = sorted(info)

@@ -181,6 +181,85 @@ class SamText:
                 for p in sorted(cols)]
 
 
+def flags_from_pileup_text(lines):
+    """{pos: (has_insert, has_delete)} exactly as StrainCall.cpp:705-736 reads pileup text:
+    '+' anywhere in field 5 -> insert, '-' or '*' anywhere -> delete (which also catches
+    the '^'+mapq characters '+', '-', '*')."""
+    info = {}
+    for line in lines:
+        f = line.split()
+        if len(f) < 2:
+            continue
+        f5 = f[4] if len(f) > 4 else ""
+        info[int(f[1])] = ("+" in f5, ("-" in f5) or ("*" in f5))
+    return info
+
+
+def _sam_pileup_flags(self, mq, region):
+    """Same result as flags_from_pileup_text(self.mpileup(mq, region)) without building the text."""
+    import numpy as np
+    name, a0, b0 = parse_region(region)
+    lo = a0 if a0 is not None else 1
+    recs = self.by_ref.get(name, ())
+    hi = b0
+    if hi is None:
+        hi = max([_ref_span(int(f[3]), f[5])[1] for _, f in recs] + [1])
+    n = hi - lo + 3
+    cover = np.zeros(n + 1, dtype=np.int64)
+    ins = np.zeros(n + 1, dtype=bool)
+    dele = np.zeros(n + 1, dtype=bool)
+
+    def mark(arr, p):
+        if lo <= p <= hi:
+            arr[p - lo] = True
+
+    for line, f in recs:
+        flag = int(f[1])
+        if flag & 1796 or int(f[4]) < mq:
+            continue
+        pos = int(f[3])
+        s, e = _ref_span(pos, f[5])
+        if e < lo or s > hi:
+            continue
+        ops = [(int(k), op) for k, op in _CIG.findall(f[5]) if op not in "HP"]
+        mapq_ch = chr(33 + min(int(f[4]), 93))
+        p, first = pos, True
+        for k, (ln, op) in enumerate(ops):
+            if op in "M=X":
+                a, b = max(p, lo), min(p + ln - 1, hi)
+                if a <= b:
+                    cover[a - lo] += 1
+                    cover[b - lo + 1] -= 1
+                if first:
+                    if mapq_ch == "+":
+                        mark(ins, p)
+                    elif mapq_ch in "-*":
+                        mark(dele, p)
+                    first = False
+                if k + 1 < len(ops):
+                    op2 = ops[k + 1][1]
+                    if op2 == "I":
+                        mark(ins, p + ln - 1)
+                    elif op2 == "D":
+                        mark(dele, p + ln - 1)
+                p += ln
+            elif op in "DN":
+                a, b = max(p, lo), min(p + ln - 1, hi)
+                if a <= b:
+                    cover[a - lo] += 1
+                    cover[b - lo + 1] -= 1
+                    dele[a - lo:b - lo + 1] = True
+                p += ln
+    depth = np.cumsum(cover[:n])
+    out = {}
+    for k in np.nonzero(depth > 0)[0]:
+        out[int(k) + lo] = (bool(ins[k]), bool(dele[k]))
+    return out
+
+
+SamText.pileup_flags = _sam_pileup_flags
+
+
 class Alignments:
     """view/mpileup provider for a mapping file (SAM text or BAM)."""
 
@@ -198,3 +277,9 @@ class Alignments:
         if self.bam:   # StrainCall.cpp:696
             return _run_samtools(["mpileup", "-q", str(mq), "-Q0", "-A", "-r", region, self.path])
         return self.sam.mpileup(mq, region)
+
+    def pileup_flags(self, mq, region):
+        """What window_adjust extracts from the pileup (StrainCall.cpp:702-736)."""
+        if self.bam:
+            return flags_from_pileup_text(self.mpileup(mq, region))
+        return self.sam.pileup_flags(mq, region)

@@ -84,7 +84,7 @@ def prepare_region(roi, fasta, bam, opts=None, shared=None):
     return pa, out
 
 
-def run_regions(ctx, prepared, streams=1):
+def run_regions(ctx, prepared, streams=1, params=None):
     """prepared: list of (pa, [(window, reads)]).  Submits every window, `streams`
     in flight, returns the FASTA text of each entry of `prepared`."""
     from . import capi
@@ -100,11 +100,11 @@ def run_regions(ctx, prepared, streams=1):
             stats.append(res.stats)
 
     for idx, (pa, regs) in enumerate(prepared):
-        params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate))
+        p_ = params or capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate))
         for wi, (window, reads) in enumerate(regs):
             if len(reads) == 0:
                 continue
-            pending.append((idx, wi, window, pa, ctx.submit(reads, params)))
+            pending.append((idx, wi, window, pa, ctx.submit(reads, p_)))
             drain(max(streams, 1))
     drain(0)
     return ["".join(t for _, t in sorted(x)) for x in texts], stats
@@ -166,6 +166,8 @@ def strain_call(fasta, bam, out_dir=None, prefix="rambl", opts=None, device=0, s
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
     mine = lpt_shards(costs, world)[rank]
+    if streams > 4:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(streams, 24)))   # one hardware queue per region in flight
     shared = (samio.Fasta(fasta), fai, samio.Alignments(bam))
     prepared = [prepare_region(rois[i], fasta, bam, opts, shared) for i in mine]
     with capi.Context(device, streams) as ctx:

@@ -149,3 +149,15 @@ def test_crop_and_cigar_helpers():
     assert ingest.crop_read_within_window(5, 8, "ACGTACGTAC", "IIIIIIIIII", cig, 3, 12) == ("GTAC", "4M")
     assert ingest.crop_read_within_window(1, 100, "ACGTACGTAC", "IIIIIIIIII", cig, 3, 12) == ("ACGTACGTAC", "10M")
     assert ingest.max_insert_size("5M3I2M7I1M") == 7
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 5, 6, 13])
+def test_pileup_flags_equal_pileup_text(seed, tmp_path):
+    """The array-based pileup summary equals the summary of the emulated pileup text."""
+    from rambl_amd import samio
+    args = T.make_case(seed, str(tmp_path))
+    aln = samio.Alignments(args[-1])
+    name = "g%d" % seed
+    for region in ("%s:1-5000" % name, "%s:40-180" % name, "%s:200-260" % name):
+        for mq in (0, 50):
+            assert aln.pileup_flags(mq, region) == samio.flags_from_pileup_text(aln.mpileup(mq, region))
