@@ -215,10 +215,6 @@ int Worker::msa_device(const std::vector<std::string>& seqs, std::vector<std::st
     return ncol;
 }
 
-static inline double logprob_tab(const HStrain& s, int a, int b) {      // Strain.cpp:132-135
-    const double c = a < 6 ? s.comp[a] : 0.0;
-    return std::log(s.sub[a * KMAX + b]) - std::log(c);
-}
 static void recount(HStrain& s) {                                         // Strain.cpp:115-124
     s.Z = 0;
     for (int i = 0; i < 6; i++) {
@@ -393,8 +389,10 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             P.a0[s] = sv[s].abundance;
             P.logpri[s] = std::log(sv[s].abundance / za);
             double* lp = P.lpt + (size_t)s * KK;
-            for (int a = 0; a < KMAX; a++)
-                for (int b = 0; b < KMAX; b++) lp[a * KMAX + b] = (a < K && b < K) ? logprob_tab(sv[s], a, b) : 0.0;
+            for (int a = 0; a < KMAX; a++) {
+                const double lc = (a < K) ? std::log(a < 6 ? sv[s].comp[a] : 0.0) : 0.0;   // log comp_count[a], Strain.cpp:132-135
+                for (int b = 0; b < KMAX; b++) lp[a * KMAX + b] = (a < K && b < K) ? std::log(sv[s].sub[a * KMAX + b]) - lc : 0.0;
+            }
         }
         const size_t bytes = offsetof(LevelParams, lpt) + sizeof(double) * (size_t)S * KK;
         HIPCHK(hipMemcpyAsync(Pd, Ph, bytes, hipMemcpyHostToDevice, st));

@@ -107,3 +107,52 @@ def test_regions_in_flight_are_independent(tmp_path):
     with capi.Context(0, 4) as ctx:
         texts, _ = stage5.run_regions(ctx, prepared, streams=4)
     assert texts == single
+
+
+def test_unthinned_deep_coverage_no_sweeps(tmp_path, oracle_bin):
+    """More than 40 000 read copies per level: the sweep count min(5000, 40000/copies) is 0
+    (NonparametricClustering.cpp:160) and np_bayes_clustering degenerates; -D large keeps every read."""
+    from rambl_amd import synth
+    d = str(tmp_path)
+    gene = synth.make_gene(77, glen=170, n_strains=2, n_reads=42000, rlen=150, err=0.0002, n_sub=3, n_ins=0, n_del=0,
+                           name="deep")
+    fa, sam = synth.write_dataset(d, [gene])
+    args = ["-r", "deep:1-170", "-q", "0", "-D", "1000000", "-I", "13", "-l", "70", "-t", "0.02", "-d", "0.02", "-w", "5000", fa, sam]
+    exp_fa, exp_tr = T.run_oracle(args, d, trace=True)
+    tf = os.path.join(d, "p.trace")
+    assert T.run_product(args, trace_file=tf) == exp_fa
+    T.compare_traces(open(tf).read(), exp_tr)
+
+
+def test_more_than_seven_symbols_is_reported_not_guessed(tmp_path):
+    """Labels with more than 7 distinct symbols are outside the device model: SC_ERR_UNSUPPORTED."""
+    from rambl_amd import capi, synth
+    d = str(tmp_path)
+    gene = synth.make_gene(5, glen=300, n_strains=1, n_reads=60, rlen=120, err=0.0, n_sub=0, n_ins=0, n_del=0, name="odd")
+    lines = []
+    for k, ln in enumerate(gene["sam_lines"]):
+        f = ln.split("\t")
+        if k % 7 == 0:
+            s = list(f[9])
+            s[10] = "RY"[k % 2]       # IUPAC codes: two extra symbols on top of A C G T - =
+            f[9] = "".join(s)
+        lines.append("\t".join(f))
+    gene["sam_lines"] = lines
+    fa, sam = synth.write_dataset(d, [gene])
+    args = ["-r", "odd:1-300"] + T.RAMBL_ARGS + [fa, sam]
+    with pytest.raises(capi.StrainCallError) as e:
+        T.run_product(args)
+    assert e.value.code == -4
+
+
+def test_process_boundary_bin_straincall(tmp_path, oracle_bin):
+    """bin/StrainCall as rambl.py launches it: argv in, FASTA on stdout, nothing else."""
+    import subprocess
+    import sys
+    d = str(tmp_path)
+    args = T.make_case(8, d)
+    exp_fa, _ = T.run_oracle(args, d)
+    p = subprocess.run([sys.executable, os.path.join(T.ROOT, "bin", "StrainCall")] + args, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-1000:]
+    assert p.stdout.decode() == exp_fa
