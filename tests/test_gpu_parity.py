@@ -156,3 +156,22 @@ def test_process_boundary_bin_straincall(tmp_path, oracle_bin):
                        stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-1000:]
     assert p.stdout.decode() == exp_fa
+
+
+def test_stage5_many_regions_one_gpu(tmp_path, oracle_bin):
+    """rambl.py stage 5 on one FASTA/SAM with several seed genes (BASELINE configs[2] in small):
+    per-region FASTA, concatenation in .fai order -- equal to running the oracle per region."""
+    from rambl_amd import stage5, synth
+    d = str(tmp_path)
+    genes = [synth.make_gene(300 + k, glen=260 + 20 * k, n_strains=1 + k % 3, n_reads=120 + 30 * k, rlen=110, err=0.004,
+                             n_sub=5, n_ins=k % 2, n_del=(k + 1) % 2, name="otu%d" % k) for k in range(5)]
+    fa, sam = synth.write_dataset(d, genes)
+    expected = ""
+    for roi in stage5.roi_list(fa + ".fai"):
+        out, _ = T.run_oracle(stage5.straincall_argv(roi, fa, sam), d)
+        expected += out
+    got = stage5.strain_call(fa, sam, out_dir=os.path.join(d, "work"), prefix="rambl", streams=3)
+    assert got == expected
+    assert open(os.path.join(d, "work", "rambl.fa")).read() == expected
+    for roi in stage5.roi_list(fa + ".fai"):
+        assert os.path.exists(os.path.join(d, "work", "3_straincall_results", "%s.fa" % roi))
