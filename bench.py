@@ -71,11 +71,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SC_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse N > 1 on a one-GPU box
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
 
     from rambl_amd import capi, cli, stage5, synth
     d = tempfile.mkdtemp(prefix="scbench_%d_" % rank)
@@ -115,7 +118,7 @@ def main():
     fence()
     dt = time.time() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)   # MAX over ranks
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ctx.close()

@@ -39,6 +39,7 @@ void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node
 void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int do_update);
 void launch_chain(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int S, int Q);
 void launch_msa(hipStream_t st, const MsaDev& d);
+void launch_thread(hipStream_t st, const ThreadDev& d, int* pool_sorted);
 int init_kernels();
 
 struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
@@ -160,11 +161,14 @@ struct Worker {
         b_ll, b_has, b_isnew, b_tabA, b_tabL, b_tabLf, b_qflag, b_qcode, b_qent, b_quid, b_out_ptr, b_out_node, b_pool_ptr, b_pool_rid,
         b_pool_cn, b_isend, b_esrc, b_support;
     DevBuf m_seqs, m_off, m_cols0, m_cols1, m_counts, m_moves, m_trace, m_out;
+    DevBuf t_ref, t_pos, t_seqoff, t_seq, t_cigoff, t_cigop, t_ciglen, t_lut, t_tabs, t_pool, t_pool2;
 
     void init();
     void run();
     void process(Job& job);
     int msa_device(const std::vector<std::string>& seqs, std::vector<std::string>& rows);
+    void thread_device(const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cig,
+                       ThreadTables& T);
     void cluster(Job& job, const PoGraph& g, FlatGraph& f);
 };
 
@@ -213,6 +217,80 @@ int Worker::msa_device(const std::vector<std::string>& seqs, std::vector<std::st
     for (int c = 0; c < ncol; c++)
         for (int k = 0; k < n; k++) rows[k][c] = cols[(size_t)c * n + k];
     return ncol;
+}
+
+
+// a5 on the device: packs the read batch, runs k_thread_* and returns the class tables.
+void Worker::thread_device(const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cig,
+                           ThreadTables& T) {
+    const int glen = (int)G.size(), n = (int)R.size();
+    // symbol table of the window: A C G T first, then every other byte that occurs, in byte order
+    bool present[256] = {false};
+    for (unsigned char c : G) present[c] = true;
+    for (const auto& r : R) for (unsigned char c : r.seq) present[c] = true;
+    std::memset(T.lut, 0xFF, sizeof T.lut);
+    T.sym.clear();
+    for (char c : {'A', 'C', 'G', 'T'}) { T.lut[(unsigned char)c] = (uint8_t)T.sym.size(); T.sym.push_back(c); }
+    for (int c = 0; c < 256; c++)
+        if (present[c] && T.lut[c] == 0xFF) {
+            if (T.sym.size() >= 8) throw ScError(SC_ERR_UNSUPPORTED, "more than 8 distinct symbols in reads and reference");
+            T.lut[c] = (uint8_t)T.sym.size(); T.sym.push_back((char)c);
+        }
+    std::vector<int> pos(n), seq_off(n + 1, 0), cig_off(n + 1, 0), cig_len;
+    std::string seq, cig_op;
+    long m_bases = 0;
+    for (int r = 0; r < n; r++) {
+        pos[r] = R[r].pos;
+        seq += R[r].seq; seq_off[r + 1] = (int)seq.size();
+        for (const CigarOp& c : cig[r]) { cig_op.push_back(c.op); cig_len.push_back(c.len); if (c.op == 'M') m_bases += c.len; }
+        cig_off[r + 1] = (int)cig_op.size();
+    }
+    const int ncls = glen * 8;
+    ThreadDev d{};
+    d.glen = glen; d.n_reads = n;
+    char* dref = (char*)t_ref.ensure((size_t)glen + 1);
+    HIPCHK(hipMemcpyAsync(dref, G.data(), (size_t)glen, hipMemcpyHostToDevice, st));
+    d.ref = dref;
+    d.pos = upload(t_pos, pos, st);
+    d.seq_off = upload(t_seqoff, seq_off, st);
+    char* dseq = (char*)t_seq.ensure(seq.size() + 1);
+    if (!seq.empty()) HIPCHK(hipMemcpyAsync(dseq, seq.data(), seq.size(), hipMemcpyHostToDevice, st));
+    d.seq = dseq;
+    d.cig_off = upload(t_cigoff, cig_off, st);
+    char* dop = (char*)t_cigop.ensure(cig_op.size() + 1);
+    if (!cig_op.empty()) HIPCHK(hipMemcpyAsync(dop, cig_op.data(), cig_op.size(), hipMemcpyHostToDevice, st));
+    d.cig_op = dop;
+    d.cig_len = upload(t_ciglen, cig_len, st);
+    uint8_t* dlut = (uint8_t*)t_lut.ensure(256);
+    HIPCHK(hipMemcpyAsync(dlut, T.lut, 256, hipMemcpyHostToDevice, st));
+    d.lut = dlut;
+    // tables: count | minrid | smin | emin (ncls each) | tmin (8*ncls) | off (ncls+1) | cursor (ncls) | err
+    const size_t words = (size_t)ncls * 4 + (size_t)ncls * 8 + (size_t)ncls + 1 + (size_t)ncls + 1;
+    int* tabs = (int*)t_tabs.ensure(sizeof(int) * words);
+    d.count = tabs; d.minrid = tabs + ncls; d.smin = tabs + 2 * (size_t)ncls; d.emin = tabs + 3 * (size_t)ncls;
+    d.tmin = tabs + 4 * (size_t)ncls; d.off = tabs + 12 * (size_t)ncls; d.cursor = d.off + ncls + 1; d.err = d.cursor + ncls;
+    HIPCHK(hipMemsetAsync(d.count, 0, sizeof(int) * (size_t)ncls, st));
+    HIPCHK(hipMemsetAsync(d.minrid, 0x7f, sizeof(int) * (size_t)ncls * 11, st));          // minrid, smin, emin, tmin = 0x7f7f7f7f
+    HIPCHK(hipMemsetAsync(d.off, 0, sizeof(int) * ((size_t)ncls * 2 + 2), st));           // off, cursor, err
+    d.pool = (int*)t_pool.ensure(sizeof(int) * (size_t)std::max<long>(m_bases, 1));
+    int* pool_sorted = (int*)t_pool2.ensure(sizeof(int) * (size_t)std::max<long>(m_bases, 1));
+    launch_thread(st, d, pool_sorted);
+    T.count.resize(ncls); T.minrid.resize(ncls); T.smin.resize(ncls); T.emin.resize(ncls);
+    T.tmin.resize((size_t)ncls * 8); T.off.resize((size_t)ncls + 1); T.pool.resize((size_t)m_bases);
+    int err = 0;
+    HIPCHK(hipMemcpyAsync(T.count.data(), d.count, sizeof(int) * (size_t)ncls, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(T.minrid.data(), d.minrid, sizeof(int) * (size_t)ncls, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(T.smin.data(), d.smin, sizeof(int) * (size_t)ncls, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(T.emin.data(), d.emin, sizeof(int) * (size_t)ncls, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(T.tmin.data(), d.tmin, sizeof(int) * (size_t)ncls * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(T.off.data(), d.off, sizeof(int) * ((size_t)ncls + 1), hipMemcpyDeviceToHost, st));
+    if (m_bases > 0) HIPCHK(hipMemcpyAsync(T.pool.data(), pool_sorted, sizeof(int) * (size_t)m_bases, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&err, d.err, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (err) throw ScError(SC_ERR_ARG, "a read runs outside the window or past its own bases");
+    const int INF = 0x7fffffff;
+    auto fix = [&](std::vector<int>& v) { for (int& x : v) if (x == 0x7f7f7f7f) x = INF; };
+    fix(T.minrid); fix(T.smin); fix(T.emin); fix(T.tmin);
 }
 
 static void recount(HStrain& s) {                                         // Strain.cpp:115-124
@@ -646,7 +724,9 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
 void Worker::process(Job& job) {
     const double t0 = now_ms();
     MsaFn msa = [this](const std::vector<std::string>& seqs, std::vector<std::string>& rows) { return msa_device(seqs, rows); };
-    PoGraph g(job.ref, job.reads, msa);
+    ThreadFn thr = [this](const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cg,
+                          ThreadTables& T) { thread_device(G, R, cg, T); };
+    PoGraph g(job.ref, job.reads, msa, thr);
     job.stats.msa_calls = g.msa_calls;
     job.graph_dump = g.dump();
     FlatGraph f;

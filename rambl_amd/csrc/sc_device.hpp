@@ -80,6 +80,21 @@ struct LevelResult {
     int error;
 };
 
+// Buffers of the read-threading kernels (k_thread_*).
+struct ThreadDev {
+    const char* ref; int glen;
+    int n_reads;
+    const int* pos; const int* seq_off; const char* seq;
+    const int* cig_off; const char* cig_op; const int* cig_len;
+    const uint8_t* lut;         // byte -> symbol code 0..7
+    int* count; int* minrid;    // [glen*8]
+    int* tmin;                  // [glen*64] first read taking class (i-1,cp) -> (i,c)
+    int* smin; int* emin;       // [glen*8] first read that starts / ends in the class
+    int* off; int* cursor;      // [glen*8 + 1]
+    int* pool;                  // [total M bases]
+    int* err;                   // nonzero: a read runs outside the window / its bases
+};
+
 // Buffers of one progressive MSA call (k_msa).
 struct MsaDev {
     const char* seqs;       // packed sequences

@@ -123,8 +123,7 @@ void std_sort_perm(std::vector<int>& idx, const std::function<bool(int, int)>& l
 }
 
 // ---------------------------------------------------------------------------
-struct Cig { char op; int len; };
-static void parse_cigar(const std::string& c, std::vector<Cig>& out) {   // cpp:13-59
+void parse_cigar(const std::string& c, std::vector<CigarOp>& out) {   // cpp:13-59
     int v = 0;
     for (char ch : c) {
         switch (ch) {
@@ -542,8 +541,200 @@ void PoGraph::finalize_ids() {
         if (nodes[i].alive) { nodes[i].id = (int)order_.size(); order_.push_back(i); }
 }
 
+// cpp:94-255, the read loop.  The per-base work (class of every M-aligned base,
+// pools, first read of every class / transition) comes from the device tables;
+// this routine replays node creations and add_edge calls in the order the
+// reference makes them -- by read, then by position inside the read -- and walks
+// only the reads that contain insertions or deletions (their private chains).
+void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>& R, const ThreadFn& thread) {
+    const int glen = (int)G.size();
+    const int n = (int)R.size();
+    std::vector<std::vector<CigarOp>> cig(n);
+    std::vector<char> complex_read(n, 0);
+    for (int r = 0; r < n; r++) {
+        parse_cigar(R[r].cigar, cig[r]);
+        for (const CigarOp& c : cig[r]) {
+            if (c.op == 'I' || c.op == 'D') complex_read[r] = 1;
+            else if (c.op != 'M') throw std::runtime_error("CIGAR operation other than M/I/D/=/X in a cropped read");
+        }
+    }
+    ThreadTables T;
+    thread(G, R, cig, T);
+    const int INF = 0x7fffffff;
+    if ((int)T.sym.size() > 8) throw std::runtime_error("more than 8 distinct read/reference symbols");
+
+    enum { EV_SIB = 0, EV_CHAIN = 1, EV_EDGE = 2 };
+    enum { REF_CLASS = 0, REF_NODE = 1, REF_CHAIN = 2 };
+    struct NodeRef { int type, a, b; };                 // CLASS: (i, c); NODE: node index; CHAIN: (chain id, position)
+    struct Event {
+        int rid, op, t, kind;
+        int i, c;                                       // EV_SIB
+        int chain;                                      // EV_CHAIN
+        NodeRef u, v; bool force, check_ne;             // EV_EDGE
+    };
+    struct Chain { int st; std::string labels; int rid; std::vector<int> nodes; };
+    std::vector<Event> ev;
+    std::vector<Chain> chains;
+
+    // (op index, offset) of reference position i inside read r, for ordering
+    auto locate = [&](int r, int i, int& op, int& t) {
+        if (!complex_read[r]) { op = 0; t = i - R[r].pos; return; }
+        int ri = R[r].pos;
+        for (int k = 0; k < (int)cig[r].size(); k++) {
+            const CigarOp& c = cig[r][k];
+            if (c.op == 'M') { if (i < ri + c.len) { op = k; t = i - ri; return; } ri += c.len; }
+            else if (c.op == 'D') ri += c.len;
+        }
+        op = (int)cig[r].size(); t = 0;
+    };
+    auto class_ref = [&](int i, int c) { return NodeRef{REF_CLASS, i, c}; };
+    auto ref_code = [&](int i) { return (int)T.lut[(unsigned char)G[i]]; };
+
+    for (int i = 0; i < glen; i++) {
+        const int gc = ref_code(i);
+        for (int c = 0; c < 8; c++) {
+            const int cls = i * 8 + c;
+            if (T.count[cls] == 0) continue;
+            int op, t;
+            if (c != gc) {                               // first read of a "mis" class creates the sibling (:151-163)
+                locate(T.minrid[cls], i, op, t);
+                Event e{}; e.rid = T.minrid[cls]; e.op = op; e.t = t; e.kind = EV_SIB; e.i = i; e.c = c;
+                ev.push_back(e);
+            }
+            if (T.smin[cls] != INF && c != gc) {         // read starts here: edge from the backbone node before it
+                const int r = T.smin[cls];
+                Event e{}; e.rid = r; e.op = 0; e.t = 0; e.kind = EV_EDGE;
+                e.u = NodeRef{REF_NODE, R[r].pos, 0}; e.v = class_ref(i, c); e.force = false; e.check_ne = false;
+                ev.push_back(e);
+            }
+            if (T.emin[cls] != INF && c != gc) {         // read ends here: edge to the next backbone node (:252-253)
+                const int r = T.emin[cls];
+                Event e{}; e.rid = r; e.op = 1 << 29; e.t = 0; e.kind = EV_EDGE;
+                e.u = class_ref(i, c); e.v = NodeRef{REF_NODE, i + 2, 0}; e.force = false; e.check_ne = true;
+                ev.push_back(e);
+            }
+            if (i > 0) {
+                const int gp = ref_code(i - 1);
+                for (int cp = 0; cp < 8; cp++) {
+                    const int r = T.tmin[i * 64 + cp * 8 + c];
+                    if (r == INF || (cp == gp && c == gc)) continue;    // backbone -> backbone is linked from the start
+                    locate(r, i, op, t);
+                    Event e{}; e.rid = r; e.op = op; e.t = t; e.kind = EV_EDGE;
+                    e.u = class_ref(i - 1, cp); e.v = class_ref(i, c); e.force = false; e.check_ne = false;
+                    ev.push_back(e);
+                }
+            }
+        }
+    }
+    // reads with insertions / deletions: their private chains and the edges around them
+    for (int r = 0; r < n; r++) {
+        if (!complex_read[r]) continue;
+        const AlignedRead& rd = R[r];
+        const int rlen = (int)rd.seq.size();
+        int i = rd.pos, j = 0;
+        NodeRef u{REF_NODE, rd.pos, 0};                  // nodes[pos]: the backbone node before the first base
+        bool u_is_end = false;
+        const int nops = (int)cig[r].size();
+        for (int k = 0; k < nops; k++) {
+            const CigarOp& c = cig[r][k];
+            if (c.op == 'M') {
+                if (i + c.len > glen || j + c.len > rlen) throw std::runtime_error("read runs past the window");
+                const int cfirst = T.lut[(unsigned char)rd.seq[j]];
+                if (k > 0 && cig[r][k - 1].op != 'M') {  // first base after a chain: edge from its tail (:141-174)
+                    Event e{}; e.rid = r; e.op = k; e.t = 0; e.kind = EV_EDGE;
+                    e.u = u; e.v = class_ref(i, cfirst); e.force = false; e.check_ne = false;
+                    ev.push_back(e);
+                }
+                i += c.len; j += c.len;
+                u = class_ref(i - 1, T.lut[(unsigned char)rd.seq[j - 1]]);
+                u_is_end = false;
+            } else {
+                Chain ch; ch.rid = r;
+                if (c.op == 'I') {
+                    if (j + c.len > rlen) throw std::runtime_error("insertion runs past the read");
+                    ch.st = ST_INS; ch.labels = rd.seq.substr(j, c.len); j += c.len;
+                } else {
+                    ch.st = ST_DEL; ch.labels = std::string((size_t)c.len, '='); i += c.len;
+                    if (i > glen) throw std::runtime_error("deletion runs past the window");
+                }
+                const int cid = (int)chains.size();
+                chains.push_back(ch);
+                Event e{}; e.rid = r; e.op = k; e.t = 0; e.kind = EV_CHAIN; e.chain = cid;
+                ev.push_back(e);
+                Event l{}; l.rid = r; l.op = k; l.t = 0; l.kind = EV_EDGE;          // add_edge(u, gap) (:190, :217)
+                l.u = u; l.v = NodeRef{REF_CHAIN, cid, 0}; l.force = true; l.check_ne = false;
+                ev.push_back(l);
+                if (c.op == 'D' && i == glen) {                                    // deletion up to "$" (:209-215)
+                    Event m{}; m.rid = r; m.op = k; m.t = 1; m.kind = EV_EDGE;
+                    m.u = NodeRef{REF_CHAIN, cid, c.len - 1}; m.v = NodeRef{REF_NODE, glen + 1, 0}; m.force = true; m.check_ne = false;
+                    ev.push_back(m);
+                    u = NodeRef{REF_NODE, glen + 1, 0};
+                    u_is_end = true;
+                } else {
+                    u = NodeRef{REF_CHAIN, cid, c.len - 1};
+                    u_is_end = false;
+                }
+            }
+        }
+        if (nops > 0 && cig[r][nops - 1].op != 'M') {    // final `if (!linking(u,v) and u!=v) add_edge(u,v)` (:252-253)
+            if (i + 1 >= (int)nodes.size()) throw std::runtime_error("read runs past the window");
+            Event e{}; e.rid = r; e.op = 1 << 29; e.t = 0; e.kind = EV_EDGE;
+            e.u = u; e.v = NodeRef{REF_NODE, i + 1, 0}; e.force = false; e.check_ne = true;
+            ev.push_back(e);
+            (void)u_is_end;
+        }
+    }
+    std::stable_sort(ev.begin(), ev.end(), [](const Event& a, const Event& b) {
+        if (a.rid != b.rid) return a.rid < b.rid;
+        if (a.op != b.op) return a.op < b.op;
+        if (a.t != b.t) return a.t < b.t;
+        return a.kind < b.kind;
+    });
+    // replay
+    std::vector<int> class_node((size_t)glen * 8, -1);
+    for (int i = 0; i < glen; i++) class_node[(size_t)i * 8 + ref_code(i)] = i + 1;
+    auto resolve = [&](const NodeRef& x) -> int {
+        if (x.type == REF_NODE) return x.a;
+        if (x.type == REF_CLASS) return class_node[(size_t)x.a * 8 + x.b];
+        return chains[x.a].nodes[x.b];
+    };
+    for (const Event& e : ev) {
+        if (e.kind == EV_SIB) {
+            const int w = new_node(ST_MIS, std::string(1, T.sym[e.c]));
+            nodes[e.i + 1].sib.push_back(w);
+            class_node[(size_t)e.i * 8 + e.c] = w;
+        } else if (e.kind == EV_CHAIN) {
+            Chain& ch = chains[e.chain];
+            int prev = -1;
+            for (char lab : ch.labels) {
+                const int w = new_node(ch.st, std::string(1, lab));
+                nodes[w].pool.push_back({ch.rid, R[ch.rid].cn, std::string(1, lab)});
+                if (prev >= 0) add_edge(prev, w);
+                ch.nodes.push_back(w);
+                prev = w;
+            }
+        } else {
+            const int a = resolve(e.u), b = resolve(e.v);
+            if (a < 0 || b < 0) throw std::runtime_error("edge event before its node");
+            if (e.force || (!linking(a, b) && !(e.check_ne && a == b))) add_edge(a, b);
+        }
+    }
+    // pools of the backbone / sibling nodes, in read order
+    for (int i = 0; i < glen; i++)
+        for (int c = 0; c < 8; c++) {
+            const int cls = i * 8 + c;
+            if (T.count[cls] == 0) continue;
+            const int w = class_node[cls];
+            if (w < 0) throw std::runtime_error("class without a node");
+            auto& pool = nodes[w].pool;
+            pool.reserve((size_t)T.count[cls]);
+            const std::string lab(1, T.sym[c]);
+            for (int x = T.off[cls]; x < T.off[cls + 1]; x++) pool.push_back({T.pool[x], R[T.pool[x]].cn, lab});
+        }
+}
+
 // cpp:67-265
-PoGraph::PoGraph(const std::string& G, const std::vector<AlignedRead>& R, const MsaFn& msa) : msa_(msa) {
+PoGraph::PoGraph(const std::string& G, const std::vector<AlignedRead>& R, const MsaFn& msa, const ThreadFn& thread) : msa_(msa) {
     const int glen = (int)G.size();
     nodes.reserve((size_t)glen + 2 + R.size() / 2);
     int u = new_node(ST_MAT, "^");
@@ -554,79 +745,7 @@ PoGraph::PoGraph(const std::string& G, const std::vector<AlignedRead>& R, const 
     }
     int E = new_node(ST_MAT, "$");
     add_edge(u, E);
-
-    std::vector<Cig> cig;
-    for (int rid = 0; rid < (int)R.size(); rid++) {
-        const AlignedRead& r = R[rid];
-        u = r.pos;
-        int v = r.pos + 1;
-        int i = r.pos, j = 0, dl = 0;
-        const int rlen = (int)r.seq.size();
-        cig.clear();
-        parse_cigar(r.cigar, cig);
-        for (const Cig& c : cig) {
-            if (c.op == 'S') {
-                j += j + c.len;                       // sic, cpp:126
-                dl = 0;
-                continue;
-            } else if (c.op == 'M') {
-                for (int k = 0; k < c.len + dl; k++, j++) {
-                    char rc = j < rlen ? r.seq[j] : 0;
-                    char gc = i < glen ? G[i] : 0;
-                    int st = (gc == rc) ? ST_MAT : ST_MIS;
-                    if (v >= (int)nodes.size()) throw std::runtime_error("read runs past the window");
-                    int target;
-                    if (nodes[v].st == st && nodes[v].lab.size() == 1 && nodes[v].lab[0] == rc) {
-                        target = v;
-                        if (!linking(u, v)) add_edge(u, v);
-                    } else {
-                        target = -1;
-                        for (int s : nodes[v].sib)
-                            if (nodes[s].st == st && nodes[s].lab.size() == 1 && nodes[s].lab[0] == rc) { target = s; break; }
-                        if (target < 0) {
-                            target = new_node(st, std::string(1, rc));
-                            add_edge(u, target);
-                            nodes[v].sib.push_back(target);
-                        } else if (!linking(u, target)) add_edge(u, target);
-                    }
-                    nodes[target].pool.push_back({rid, r.cn, std::string(1, rc)});
-                    u = target;
-                    v = ++i + 1;
-                }
-                dl = 0;
-            } else if (c.op == 'I') {
-                std::vector<int> gap;
-                for (int k = 0; k < c.len; k++, j++) {
-                    std::string lab(1, j < rlen ? r.seq[j] : (char)0);
-                    int w = new_node(ST_INS, lab);
-                    nodes[w].pool.push_back({rid, r.cn, lab});
-                    gap.push_back(w);
-                }
-                add_edge_gap(u, gap);
-                if (!gap.empty()) u = gap.back();
-                dl = 0;
-            } else if (c.op == 'D') {
-                std::vector<int> gap;
-                for (int k = 0; k < c.len; k++) {
-                    int w = new_node(ST_DEL, "=");
-                    nodes[w].pool.push_back({rid, r.cn, "="});
-                    gap.push_back(w);
-                    v = ++i + 1;
-                }
-                if (v >= (int)nodes.size()) throw std::runtime_error("deletion runs past the window");
-                if (nodes[v].lab == "$") {
-                    add_edge_gap_to(u, v, gap);
-                    u = v;
-                    continue;
-                }
-                add_edge_gap(u, gap);
-                if (!gap.empty()) u = gap.back();
-                dl = 0;
-            }
-        }
-        if (v >= (int)nodes.size()) throw std::runtime_error("read runs past the window");
-        if (!linking(u, v) && u != v) add_edge(u, v);
-    }
+    thread_reads(G, R, thread);
     // canonize_graph, cpp:754-767
     for (int i = 0; i < (int)nodes.size(); ++i) {            // canonize_insert :553-564
         if (nodes[i].lab == "$") break;

@@ -41,12 +41,31 @@ struct AlignedRead {
     int cn;               // copy number (exact duplicates collapsed upstream)
 };
 
+// Parsed CIGAR, '=' and 'X' already mapped to 'M' (PartialOrderGraph.cpp:13-59).
+struct CigarOp { char op; int len; };
+void parse_cigar(const std::string& c, std::vector<CigarOp>& out);
+
+// Output of the device threading kernels (k_thread_*, row a5): every M-aligned
+// read base bucketed by (reference position i, symbol c).  Index = i*8 + c.
+struct ThreadTables {
+    uint8_t lut[256];                 // byte -> symbol code, 0xFF = not present
+    std::vector<char> sym;            // code -> byte
+    std::vector<int> count, minrid;   // [glen*8] class size, first read of the class
+    std::vector<int> tmin;            // [glen*64] first read going (i-1,cp) -> (i,c) inside an M run
+    std::vector<int> smin, emin;      // [glen*8] first read starting / ending in the class
+    std::vector<int> off;             // [glen*8+1] pool offsets
+    std::vector<int> pool;            // read ids of every class, ascending
+};
+// Produces the tables for one region (the device implementation lives in sc_api.cpp).
+using ThreadFn = std::function<void(const std::string& G, const std::vector<struct AlignedRead>& R,
+                                    const std::vector<std::vector<CigarOp>>& cigars, ThreadTables& out)>;
+
 // rows[t] = padded row of seqs[t]; returns the number of MSA columns.
 using MsaFn = std::function<int(const std::vector<std::string>& seqs, std::vector<std::string>& rows)>;
 
 class PoGraph {
 public:
-    PoGraph(const std::string& G, const std::vector<AlignedRead>& R, const MsaFn& msa);
+    PoGraph(const std::string& G, const std::vector<AlignedRead>& R, const MsaFn& msa, const ThreadFn& thread);
 
     std::vector<GNode> nodes;
     int n_alive = 0;
@@ -86,6 +105,7 @@ private:
     void path_collapse();
     void node_level();
     void finalize_ids();
+    void thread_reads(const std::string& G, const std::vector<AlignedRead>& R, const ThreadFn& thread);
 };
 
 // libstdc++ std::sort permutation (the reference depends on its tie order at

@@ -1074,6 +1074,93 @@ __global__ __launch_bounds__(256) void k_msa(MsaDev d) {
 }
 
 // --------------------------------------------------------------------------
+// a5: threading of the reads along the backbone (PartialOrderGraph.cpp:94-255,
+// the per-base M loop :129-177).  A read base aligned to reference position i
+// with symbol c lands in node class (i, c): the backbone node if c is the
+// reference base, else the "mis" sibling for that symbol.  The kernels bucket all
+// M-aligned bases of a packed read batch into those classes:
+//   k_thread_count  one wavefront per read: class sizes, first read of every class
+//                   (it creates the sibling), first read of every class-to-class
+//                   transition / read start / read end (it adds the edge)
+//   k_thread_scan   exclusive scan of the class sizes
+//   k_thread_fill   read ids into the class pools
+//   k_thread_sort   each pool into read order (the order the reference appends in)
+// The host stitches nodes and edges from these tables in first-touch order and
+// only walks the reads that contain insertions or deletions (sc_graph.cpp).
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_thread_walk(ThreadDev d) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < d.n_reads; r += nwaves) {
+        const int c0 = d.cig_off[r], c1 = d.cig_off[r + 1];
+        const int s0 = d.seq_off[r], slen = d.seq_off[r + 1] - s0;
+        int i = d.pos[r], j = 0;
+        bool prev_m = false;
+        for (int k = c0; k < c1; k++) {
+            const char op = d.cig_op[k];
+            const int len = d.cig_len[k];
+            if (op == 'M') {
+                if (i + len > d.glen || j + len > slen) { if (lane == 0) atomicOr(d.err, 1); break; }
+                for (int t = lane; t < len; t += 64) {
+                    const int c = d.lut[(unsigned char)d.seq[s0 + j + t]];
+                    const int cls = (i + t) * 8 + c;
+                    if (!FILL) {
+                        atomicAdd(&d.count[cls], 1);
+                        atomicMin(&d.minrid[cls], r);
+                        if (t > 0 || prev_m) {
+                            const int cp = d.lut[(unsigned char)d.seq[s0 + j + t - 1]];
+                            atomicMin(&d.tmin[(i + t) * 64 + cp * 8 + c], r);
+                        } else if (k == c0) {
+                            atomicMin(&d.smin[cls], r);
+                        }
+                        if (t == len - 1 && k == c1 - 1) atomicMin(&d.emin[cls], r);
+                    } else {
+                        const int p = atomicAdd(&d.cursor[cls], 1);
+                        d.pool[d.off[cls] + p] = r;
+                    }
+                }
+                i += len; j += len; prev_m = true;
+            } else if (op == 'I') { j += len; prev_m = false; }
+            else if (op == 'D') { i += len; prev_m = false; }
+            else { if (lane == 0) atomicOr(d.err, 2); break; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_thread_scan(const int* __restrict__ count, int* __restrict__ off, int n) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = tid * per, e = min(n, b + per);
+    int sum = 0;
+    for (int k = b; k < e; k++) sum += count[k];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int k = 0; k < 1024; k++) { const int v = part[k]; part[k] = acc; acc += v; } off[n] = acc; }
+    __syncthreads();
+    int acc = part[tid];
+    for (int k = b; k < e; k++) { off[k] = acc; acc += count[k]; }
+}
+
+// rank sort of every pool by read id (ids are distinct inside a class)
+__global__ __launch_bounds__(256) void k_thread_sort(const int* __restrict__ off, const int* __restrict__ in, int* __restrict__ out, int ncls) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int c = wave; c < ncls; c += nwaves) {
+        const int b = off[c], n = off[c + 1] - b;
+        for (int x = lane; x < n; x += 64) {
+            const int mine = in[b + x];
+            int rank = 0;
+            for (int y = 0; y < n; y++) rank += (in[b + y] < mine);
+            out[b + rank] = mine;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
 // host-callable launchers (called from sc_cluster.cpp / sc_api.cpp)
 void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node, const int* pool_ptr, const int* pool_rid,
                          const int* pool_cn, const uint8_t* node_is_end, const int* edge_src, int n_edges, int sorted,
@@ -1117,5 +1204,18 @@ void launch_chain(hipStream_t st, const JobDev& job, const LevelParams* P, Level
 #undef SC_CHAIN
 }
 void launch_msa(hipStream_t st, const MsaDev& d) { hipLaunchKernelGGL(k_msa, dim3(1), dim3(256), 0, st, d); }
+// a5 in four launches; `pool_sorted` receives the class pools in read order.
+void launch_thread(hipStream_t st, const ThreadDev& d, int* pool_sorted) {
+    const int ncls = d.glen * 8;
+    int blocks = (d.n_reads + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_thread_walk<false>), dim3(blocks), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_thread_scan, dim3(1), dim3(1024), 0, st, d.count, d.off, ncls);
+    hipLaunchKernelGGL((k_thread_walk<true>), dim3(blocks), dim3(256), 0, st, d);
+    int sblocks = (ncls + 3) / 4;
+    if (sblocks > 2048) sblocks = 2048;
+    hipLaunchKernelGGL(k_thread_sort, dim3(sblocks), dim3(256), 0, st, d.off, d.pool, pool_sorted, ncls);
+}
 
 }  // namespace sc
