@@ -101,12 +101,64 @@ def _ref_span(pos, cigar):
     return pos, pos + max(n, 1) - 1
 
 
-class SamText:
-    """A SAM text file held in memory, indexed by reference name."""
+def bam_records(path):
+    """Native BAM reader: BGZF is a series of gzip
+    members, the payload is the BAM record stream of the SAM specification.  Yields
+    the 11 mandatory SAM fields of every alignment as text (optional tags are not
+    needed by the path).  The whole file is inflated; there is no .bai random access."""
+    import gzip
+    import struct
+    with gzip.open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"BAM\x01":
+        raise ValueError("%s: not a BAM file" % path)
+    (l_text,) = struct.unpack_from("<i", data, 4)
+    o = 8 + l_text
+    (n_ref,) = struct.unpack_from("<i", data, o)
+    o += 4
+    refs = []
+    for _ in range(n_ref):
+        (l_name,) = struct.unpack_from("<i", data, o)
+        o += 4
+        refs.append(data[o:o + l_name - 1].decode("ascii"))
+        o += l_name + 4
+    seq_code = "=ACMGRSVTWYHKDBN"
+    cig_code = "MIDNSHP=X"
+    n = len(data)
+    while o + 4 <= n:
+        (block_size,) = struct.unpack_from("<i", data, o)
+        o += 4
+        ref_id, pos, l_read_name, mapq, _bin, n_cigar, flag, l_seq, next_ref, next_pos, tlen = struct.unpack_from(
+            "<iiBBHHHiiii", data, o)
+        p = o + 32
+        qname = data[p:p + l_read_name - 1].decode("ascii")
+        p += l_read_name
+        cig = struct.unpack_from("<%dI" % n_cigar, data, p) if n_cigar else ()
+        p += 4 * n_cigar
+        cigar = "".join("%d%s" % (c >> 4, cig_code[c & 15]) for c in cig) or "*"
+        nb = (l_seq + 1) // 2
+        sb = data[p:p + nb]
+        p += nb
+        seq = "".join(seq_code[b >> 4] + seq_code[b & 15] for b in sb)[:l_seq] or "*"
+        q = data[p:p + l_seq]
+        qual = "*" if (l_seq == 0 or q[:1] == b"\xff") else bytes(c + 33 for c in q).decode("ascii")
+        rname = refs[ref_id] if 0 <= ref_id < n_ref else "*"
+        rnext = "*" if next_ref < 0 else ("=" if next_ref == ref_id else refs[next_ref])
+        yield [qname, str(flag), rname, str(pos + 1), str(mapq), cigar, rnext, str(next_pos + 1), str(tlen), seq, qual]
+        o += block_size
 
-    def __init__(self, path):
+
+class SamText:
+    """Alignments held in memory, indexed by reference name: a SAM text file, or a
+    BAM file read natively (`bam=True`)."""
+
+    def __init__(self, path, bam=False):
         self.path = path
         self.by_ref = {}
+        if bam:
+            for fld in bam_records(path):
+                self.by_ref.setdefault(fld[2], []).append(("\t".join(fld), fld))
+            return
         with open(path) as f:
             for line in f:
                 if line.startswith("@") or not line.strip():
@@ -265,8 +317,11 @@ class Alignments:
 
     def __init__(self, path):
         self.path = path
-        self.bam = is_bam(path)
-        self.sam = None if self.bam else SamText(path)
+        # BAM: the real samtools when it is installed (exactly the reference's commands), else the
+        # native reader; SC_NATIVE_BAM=1 forces the native reader.
+        import os
+        self.bam = is_bam(path) and shutil.which("samtools") is not None and not os.environ.get("SC_NATIVE_BAM")
+        self.sam = None if self.bam else SamText(path, bam=is_bam(path))
 
     def view(self, mq, region):
         if self.bam:   # StrainCall.cpp:496

@@ -161,3 +161,67 @@ def test_pileup_flags_equal_pileup_text(seed, tmp_path):
     for region in ("%s:1-5000" % name, "%s:40-180" % name, "%s:200-260" % name):
         for mq in (0, 50):
             assert aln.pileup_flags(mq, region) == samio.flags_from_pileup_text(aln.mpileup(mq, region))
+
+
+def _write_bam(sam_path, bam_path):
+    """Minimal BAM writer (SAM spec section 4) used only to exercise the native reader."""
+    import struct
+    import zlib
+    hdr, recs, refs = [], [], []
+    for line in open(sam_path):
+        if line.startswith("@"):
+            hdr.append(line)
+            if line.startswith("@SQ"):
+                f = dict(x.split(":", 1) for x in line.rstrip().split("\t")[1:])
+                refs.append((f["SN"], int(f["LN"])))
+        elif line.strip():
+            recs.append(line.rstrip("\n").split("\t"))
+    ref_id = {n: i for i, (n, _) in enumerate(refs)}
+    text = "".join(hdr).encode()
+    out = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs)))
+    for n, l in refs:
+        out += struct.pack("<i", len(n) + 1) + n.encode() + b"\x00" + struct.pack("<i", l)
+    seq_code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    cig_code = {c: i for i, c in enumerate("MIDNSHP=X")}
+    import re
+    for f in recs:
+        qn = f[0].encode() + b"\x00"
+        cig = [(int(n), op) for n, op in re.findall(r"(\d+)([MIDNSHP=X])", f[5])]
+        seq = f[9]
+        sb = bytearray()
+        for k in range(0, len(seq), 2):
+            hi = seq_code[seq[k]]
+            lo = seq_code[seq[k + 1]] if k + 1 < len(seq) else 0
+            sb.append(hi << 4 | lo)
+        qual = bytes(ord(c) - 33 for c in f[10]) if f[10] != "*" else b"\xff" * len(seq)
+        body = struct.pack("<iiBBHHHiiii", ref_id.get(f[2], -1), int(f[3]) - 1, len(qn), int(f[4]), 0, len(cig), int(f[1]),
+                           len(seq), -1, -1, 0)
+        body += qn + b"".join(struct.pack("<I", n << 4 | cig_code[op]) for n, op in cig) + bytes(sb) + qual
+        out += struct.pack("<i", len(body)) + body
+    with open(bam_path, "wb") as g:
+        for k in range(0, len(out), 60000):          # BGZF: gzip members with the BC extra field
+            chunk = bytes(out[k:k + 60000])
+            comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+            cdata = comp.compress(chunk) + comp.flush()
+            bsize = len(cdata) + 25
+            g.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize)
+                    + cdata + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+        g.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+
+
+@pytest.mark.parametrize("seed", [2, 4])
+def test_native_bam_reader_gives_the_same_regions(seed, tmp_path, monkeypatch):
+    """BAM input read natively (no samtools in the image) yields the same ingest as the SAM text."""
+    monkeypatch.setenv("SC_NATIVE_BAM", "1")
+    d = str(tmp_path)
+    args = T.make_case(seed, d)
+    bam = os.path.join(d, "reads.bam")
+    _write_bam(args[-1], bam)
+    from rambl_amd import samio
+    assert samio.is_bam(bam)
+    a = cli.load_regions(cli.parse_cmd_line(args))
+    b = cli.load_regions(cli.parse_cmd_line(args[:-1] + [bam]))
+    assert len(a) == len(b)
+    for (wa, ra), (wb, rb) in zip(a, b):
+        assert wa == wb and ra.gene_seq == rb.gene_seq
+        assert (ra.pos, ra.cigar, ra.seq, ra.copies, ra.mates) == (rb.pos, rb.cigar, rb.seq, rb.copies, rb.mates)
