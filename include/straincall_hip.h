@@ -117,6 +117,15 @@ int sc_msa_align(sc_ctx* ctx, const char* seq_text, const int* seq_off, int n, c
  * (PartialOrderGraph.cpp:1218-1244), in the edge order of the -G dump. */
 int sc_roi_edge_support(sc_ctx* ctx, int handle, int* support, int cap, int* n_edges);
 
+/* Row a5 on its own: the class tables of the read-threading kernels for a region
+ * (the per-base M loop of PartialOrderGraph::build, PartialOrderGraph.cpp:129-177):
+ * count[i*8+c] = reads whose base aligned to window position i is symbol c,
+ * first_read[i*8+c] = the first such read (it creates the node), pool = the read ids
+ * of every class back to back in class order, ascending inside a class.
+ * symbols[8] receives the symbol of every code (0 = unused). */
+int sc_roi_thread_tables(sc_ctx* ctx, int handle, int* count, int* first_read, int cls_cap, int* pool, long pool_cap,
+                         char* symbols, int* n_cls, long* n_pool);
+
 #ifdef __cplusplus
 }
 #endif

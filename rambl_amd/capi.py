@@ -56,14 +56,16 @@ def load_library():
     lib.sc_roi_release.argtypes = [vp, C.c_int]
     lib.sc_roi_edge_support.argtypes = [vp, C.c_int, ip, C.c_int, ip]
     lib.sc_msa_align.argtypes = [vp, cp, ip, C.c_int, C.c_char_p, C.c_long, ip]
+    lib.sc_roi_thread_tables.argtypes = [vp, C.c_int, ip, ip, C.c_int, ip, C.c_long, C.c_char_p, ip, C.POINTER(C.c_long)]
     for f in ("sc_ctx_create", "sc_roi_submit", "sc_roi_wait", "sc_roi_result", "sc_roi_graph_dump", "sc_roi_trace",
-              "sc_roi_stats", "sc_roi_release", "sc_roi_edge_support", "sc_msa_align"):
+              "sc_roi_stats", "sc_roi_release", "sc_roi_edge_support", "sc_msa_align", "sc_roi_thread_tables"):
         getattr(lib, f).restype = C.c_int
     return lib
 
 
 EXPORTS = ["sc_ctx_create", "sc_ctx_destroy", "sc_last_error", "sc_roi_submit", "sc_roi_wait", "sc_roi_result",
-           "sc_roi_graph_dump", "sc_roi_trace", "sc_roi_stats", "sc_roi_release", "sc_roi_edge_support", "sc_msa_align"]
+           "sc_roi_graph_dump", "sc_roi_trace", "sc_roi_stats", "sc_roi_release", "sc_roi_edge_support", "sc_msa_align",
+           "sc_roi_thread_tables"]
 
 
 def default_params(error_rate=0.01, tau=0.02, diff_rate=0.01, graph_only=False, want_trace=False, want_timing=False):
@@ -190,6 +192,20 @@ class Context:
         if rc != SC_OK:
             raise self._err(rc)
         return list(arr[:n.value])
+
+    def thread_tables(self, handle):
+        """Row a5: (count[glen*8], first_read[glen*8], pool[], symbols) of a finished region."""
+        ncls, npool = C.c_int(), C.c_long()
+        self.lib.sc_roi_thread_tables(self.h, handle, None, None, 0, None, 0, None, C.byref(ncls), C.byref(npool))
+        cnt = (C.c_int * max(ncls.value, 1))()
+        first = (C.c_int * max(ncls.value, 1))()
+        pool = (C.c_int * max(npool.value, 1))()
+        sym = C.create_string_buffer(8)
+        rc = self.lib.sc_roi_thread_tables(self.h, handle, cnt, first, ncls.value, pool, npool.value, sym, C.byref(ncls),
+                                           C.byref(npool))
+        if rc != SC_OK:
+            raise self._err(rc)
+        return list(cnt[:ncls.value]), list(first[:ncls.value]), list(pool[:npool.value]), sym.raw
 
     def msa_align(self, seqs):
         """Row a7: rows of the progressive sum-of-pairs MSA of `seqs` (in the given order)."""

@@ -117,6 +117,8 @@ struct Job {
     std::vector<double> abund;
     std::string graph_dump, trace;
     std::vector<int> edge_support;
+    std::vector<int> thr_count, thr_first, thr_pool;
+    std::string thr_sym;
     sc_stats stats{};
     int status = 0;       // 0 queued/running, 1 done
     int rc = SC_OK;
@@ -724,8 +726,11 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
 void Worker::process(Job& job) {
     const double t0 = now_ms();
     MsaFn msa = [this](const std::vector<std::string>& seqs, std::vector<std::string>& rows) { return msa_device(seqs, rows); };
-    ThreadFn thr = [this](const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cg,
-                          ThreadTables& T) { thread_device(G, R, cg, T); };
+    ThreadFn thr = [this, &job](const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cg,
+                          ThreadTables& T) {
+        thread_device(G, R, cg, T);
+        job.thr_count = T.count; job.thr_first = T.minrid; job.thr_pool = T.pool; job.thr_sym.assign(T.sym.begin(), T.sym.end());
+    };
     PoGraph g(job.ref, job.reads, msa, thr);
     job.stats.msa_calls = g.msa_calls;
     job.graph_dump = g.dump();
@@ -950,6 +955,21 @@ int sc_roi_edge_support(sc_ctx* h, int handle, int* support, int cap, int* n_edg
     *n_edges = (int)job->edge_support.size();
     if (!support || cap < *n_edges) return SC_ERR_CAPACITY;
     std::memcpy(support, job->edge_support.data(), sizeof(int) * job->edge_support.size());
+    return SC_OK;
+}
+int sc_roi_thread_tables(sc_ctx* h, int handle, int* count, int* first_read, int cls_cap, int* pool, long pool_cap,
+                         char* symbols, int* n_cls, long* n_pool) {
+    if (!h || !n_cls || !n_pool) return SC_ERR_ARG;
+    auto job = find_job(h, handle);
+    if (!job || job->status != 1) return SC_ERR_ARG;
+    *n_cls = (int)job->thr_count.size();
+    *n_pool = (long)job->thr_pool.size();
+    if (!count || !first_read || !pool || !symbols || cls_cap < *n_cls || pool_cap < *n_pool) return SC_ERR_CAPACITY;
+    std::memcpy(count, job->thr_count.data(), sizeof(int) * job->thr_count.size());
+    std::memcpy(first_read, job->thr_first.data(), sizeof(int) * job->thr_first.size());
+    std::memcpy(pool, job->thr_pool.data(), sizeof(int) * job->thr_pool.size());
+    std::memset(symbols, 0, 8);
+    std::memcpy(symbols, job->thr_sym.data(), std::min<size_t>(8, job->thr_sym.size()));
     return SC_OK;
 }
 int sc_roi_release(sc_ctx* h, int handle) {

@@ -691,7 +691,12 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
         const double2* src = reinterpret_cast<const double2*>(job.ll + (long)P->copy_src[c] * stride);
         double2* dst = reinterpret_cast<double2*>(job.ll + (long)P->copy_dst[c] * stride);
         const int n2 = (job.n_reads + 1) >> 1;
-        for (int i = tid; i < n2; i += nt) dst[i] = src[i];
+        int i = tid;
+        for (; i + 3 * nt < n2; i += 4 * nt) {        // four independent 16-byte loads in flight per thread
+            const double2 v0 = src[i], v1 = src[i + nt], v2 = src[i + 2 * nt], v3 = src[i + 3 * nt];
+            dst[i] = v0; dst[i + nt] = v1; dst[i + 2 * nt] = v2; dst[i + 3 * nt] = v3;
+        }
+        for (; i < n2; i += nt) dst[i] = src[i];
         __syncthreads();                       // a later copy may read this row
     }
     for (int i = tid; i < MAXS * KMAX; i += nt) s_cnt[i] = 0;
@@ -805,10 +810,12 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
                 const double* prow = job.tabA + (long)s * job.qcap;
                 double acc = 0;
                 if (b == K) {
+#pragma unroll 8
                     for (int q = 0; q < Q; q++) acc += prow[q];
                     R->abund[s] = acc;
                 } else {
-                    for (int q = 0; q < Q; q++) if (job.qcode[q] == b) acc += prow[q];
+#pragma unroll 8
+                    for (int q = 0; q < Q; q++) acc += (job.qcode[q] == b) ? prow[q] : 0.0;
                     const int a = job.labels[s_laboff[s]];
                     s_tab[s * KK + a * KMAX + b] = acc;
                 }
@@ -1144,18 +1151,53 @@ __global__ __launch_bounds__(1024) void k_thread_scan(const int* __restrict__ co
     for (int k = b; k < e; k++) { off[k] = acc; acc += count[k]; }
 }
 
-// rank sort of every pool by read id (ids are distinct inside a class)
+// every pool into ascending read order (ids are distinct inside a class).  Reads are sorted by
+// start position, so the reads of one class span a short id range: a bitmap of that range in LDS
+// gives every read its rank with two popcounts; wider ranges fall back to a quadratic rank sort.
 __global__ __launch_bounds__(256) void k_thread_sort(const int* __restrict__ off, const int* __restrict__ in, int* __restrict__ out, int ncls) {
-    const int lane = threadIdx.x & 63;
+    constexpr int WORDS = 256;                       // 8192 ids per wavefront
+    __shared__ unsigned bits[4][WORDS];
+    __shared__ int wpre[4][WORDS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int c = wave; c < ncls; c += nwaves) {
         const int b = off[c], n = off[c + 1] - b;
-        for (int x = lane; x < n; x += 64) {
-            const int mine = in[b + x];
-            int rank = 0;
-            for (int y = 0; y < n; y++) rank += (in[b + y] < mine);
-            out[b + rank] = mine;
+        if (n <= 0) continue;
+        if (n == 1) { if (lane == 0) out[b] = in[b]; continue; }
+        int lo = 0x7fffffff, hi = -1;
+        for (int x = lane; x < n; x += 64) { const int v = in[b + x]; lo = min(lo, v); hi = max(hi, v); }
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        if (hi - lo < WORDS * 32) {
+            const int nw = ((hi - lo) >> 5) + 1;
+            for (int k = lane; k < nw; k += 64) bits[w][k] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            for (int x = lane; x < n; x += 64) { const int v = in[b + x] - lo; atomicOr(&bits[w][v >> 5], 1u << (v & 31)); }
+            __builtin_amdgcn_wave_barrier();
+            // exclusive prefix of the word popcounts (nw <= 256: four words per lane)
+            int run = 0;
+            for (int k0 = 0; k0 < nw; k0 += 64) {
+                const int k = k0 + lane;
+                const int pc = (k < nw) ? __popc(bits[w][k]) : 0;
+                int incl = pc;
+                for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+                if (k < nw) wpre[w][k] = run + incl - pc;
+                run += __shfl(incl, 63);
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int x = lane; x < n; x += 64) {
+                const int rid = in[b + x], v = rid - lo;
+                const int rank = wpre[w][v >> 5] + __popc(bits[w][v >> 5] & ((1u << (v & 31)) - 1u));
+                out[b + rank] = rid;
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            for (int x = lane; x < n; x += 64) {
+                const int mine = in[b + x];
+                int rank = 0;
+                for (int y = 0; y < n; y++) rank += (in[b + y] < mine);
+                out[b + rank] = mine;
+            }
         }
     }
 }

@@ -175,3 +175,46 @@ def test_stage5_many_regions_one_gpu(tmp_path, oracle_bin):
     assert open(os.path.join(d, "work", "rambl.fa")).read() == expected
     for roi in stage5.roi_list(fa + ".fai"):
         assert os.path.exists(os.path.join(d, "work", "3_straincall_results", "%s.fa" % roi))
+
+
+@pytest.mark.parametrize("seed", [1, 3, 7, 13])
+def test_thread_kernels_class_tables(seed, tmp_path):
+    """k_thread_* (row a5) against a plain restatement of the per-base M loop
+    (PartialOrderGraph.cpp:129-177): class sizes, first read per class, pools in read order."""
+    from rambl_amd import capi, cli, ingest
+    args = T.make_case(seed, str(tmp_path))
+    pa = cli.parse_cmd_line(args)
+    params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate), graph_only=True)
+    with capi.Context(0, 1) as ctx:
+        for window, reads in cli.load_regions(pa):
+            if len(reads) == 0:
+                continue
+            h = ctx.submit(reads, params)
+            ctx.wait(h, release=False)
+            cnt, first, pool, sym = ctx.thread_tables(h)
+            ctx.lib.sc_roi_release(ctx.h, h)
+            code = {ch: k for k, ch in enumerate(sym) if ch}
+            glen = len(reads.gene_seq)
+            exp = {}
+            for rid in range(len(reads)):
+                i, j = reads.pos[rid], 0
+                for op, ln in ingest.parse_cigar(reads.cigar[rid]):
+                    if op == "M":
+                        for t in range(ln):
+                            exp.setdefault((i + t) * 8 + code[ord(reads.seq[rid][j + t])], []).append(rid)
+                        i += ln
+                        j += ln
+                    elif op == "I":
+                        j += ln
+                    elif op == "D":
+                        i += ln
+            assert len(cnt) == glen * 8
+            off = 0
+            for cls in range(glen * 8):
+                members = exp.get(cls, [])
+                assert cnt[cls] == len(members)
+                assert pool[off:off + cnt[cls]] == members          # ascending read ids
+                if members:
+                    assert first[cls] == members[0]
+                off += cnt[cls]
+            assert off == len(pool)
