@@ -961,36 +961,52 @@ __device__ __forceinline__ int dna_score_cls(int x, int y) {
 }
 
 
+constexpr int MSA_CM = 1024;                       // widest alignment (columns) kept in LDS
+constexpr size_t MSA_LDS = 2 * MSA_CM * 10 * sizeof(unsigned short) + 2 * MSA_CM + (MSA_CM + 1) * 64 + 2 * (MSA_CM + 64) * sizeof(int);
+
 __global__ __launch_bounds__(256) void k_msa(MsaDev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char m_raw[];
+    unsigned short* s_cnt = reinterpret_cast<unsigned short*>(m_raw);            // [2][MSA_CM][10] class counts per column
+    char* s_c0 = reinterpret_cast<char*>(s_cnt + 2 * MSA_CM * 10);                // [2][MSA_CM] row-0 character per column
+    unsigned char* s_mv = reinterpret_cast<unsigned char*>(s_c0 + 2 * MSA_CM);    // [(MSA_CM+1)][64] traceback moves
+    int* s_trace = reinterpret_cast<int*>(s_mv + (MSA_CM + 1) * 64);              // [2*(MSA_CM+64)]
     __shared__ int s_ncol, s_newn, s_err;
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
     const int n = d.n;
     int cur = 0;
-    if (tid == 0) { s_ncol = d.seq_off[1] - d.seq_off[0]; s_err = 0; }
+    if (tid == 0) { s_ncol = d.seq_off[1] - d.seq_off[0]; s_err = (s_ncol > MSA_CM || n > 65535) ? 1 : 0; }
     __syncthreads();
-    {   // first sequence: one column per character
+    if (!s_err) {   // first sequence: one column per character
         const int l0 = s_ncol;
         for (int c = tid; c < l0; c += nt) {
-            d.cols[0][(long)c * n + 0] = d.seqs[d.seq_off[0] + c];
-            for (int k = 0; k < 11; k++) d.counts[c * 11 + k] = 0;
-            d.counts[c * 11 + cls_of(d.seqs[d.seq_off[0] + c])] = 1;
+            const char ch = d.seqs[d.seq_off[0] + c];
+            d.cols[0][(long)c * n + 0] = ch;
+            for (int k = 0; k < 10; k++) s_cnt[c * 10 + k] = 0;
+            const int cl = cls_of(ch);
+            if (cl < 10) s_cnt[c * 10 + cl] = 1;
+            s_c0[c] = ch;
         }
     }
     __syncthreads();
-    for (int t = 1; t < n; t++) {
+    for (int t = 1; t < n && !s_err; t++) {
         const int s = t;                                  // rows already aligned
         const int ncol = s_ncol;
         const int m = ncol + 1;
         const char* seq = d.seqs + d.seq_off[t];
         const int len = d.seq_off[t + 1] - d.seq_off[t];
         const int nn = len + 1;
-        if (nn > 64 || ncol + len > d.cmax) { if (tid == 0) s_err = 1; __syncthreads(); break; }
+        if (nn > 64 || ncol + len > MSA_CM || ncol + len > d.cmax) { if (tid == 0) s_err = 1; __syncthreads(); break; }
         const char* colc = d.cols[cur];
+        const unsigned short* cntc = s_cnt + cur * MSA_CM * 10;
+        const char* c0c = s_c0 + cur * MSA_CM;
         // ---- forward, wave 0: lane j = DP column j, time step tau handles row i = tau - j
         if (tid < 64) {
             const int j = lane;
             const int b = (j >= 1 && j < nn) ? cls_of(seq[j - 1]) : 10;
-            // column j = 0 boundary values are produced by lane 0 as it walks i
+            int scb[9];
+#pragma unroll
+            for (int c = 0; c < 9; c++) scb[c] = dna_score_cls(c, b);
+            const int sb_minus = dna_score_cls(9, b), sb_plus = dna_score_cls(8, b);
             int sc_up = 0;          // SC[i-1][j]
             int st_up = 0;          // state of cell (i-1, j): 0 mat, 1 ins, 2 del
             // row 0: SC[0][j] = s*(-6) + (j-1)*s*(-2), state ins for j >= 1, mat at j = 0
@@ -1003,33 +1019,33 @@ __global__ __launch_bounds__(256) void k_msa(MsaDev d) {
                 const int st_l = __shfl_up(st_up, 1);
                 int sc_new = sc_up, st_new = st_up;
                 if (i >= 1 && i < m && j < nn) {
-                    const int* cnt = d.counts + (i - 1) * 11;
+                    const unsigned short* cnt = cntc + (i - 1) * 10;
                     if (j == 0) {
                         int sp = 0;
                         const int y = (i == 1) ? 8 : 9;
-                        for (int c = 0; c < 10; c++) sp += cnt[c] * dna_score_cls(c, y);
+#pragma unroll
+                        for (int c = 0; c < 10; c++) sp += (int)cnt[c] * dna_score_cls(c, y);
                         sc_new = sc_up + sp;
                         st_new = 3;                       // per-row state, never ins and never uniform-del
-                        d.moves[i * 64 + 0] = 2;
                     } else {
                         const int nd = cnt[9];
-                        const char c0 = colc[(long)(i - 1) * n + 0];
-                        // diagonal: cell (i-1, j-1)
-                        int r1 = 0;
-                        for (int c = 0; c < 9; c++) r1 += cnt[c] * dna_score_cls(c, b);
-                        r1 += nd * dna_score_cls(st_left_prev == 1 ? 9 : 8, b);
-                        r1 += sc_left_prev;
-                        // insert: cell (i, j-1)
-                        int r2 = s * dna_score_cls(st_l == 1 ? 9 : 8, b) + sc_l;
-                        // delete: cell (i-1, j)
-                        int r3 = 0;
+                        const char c0 = c0c[i - 1];
+                        int r1 = 0, r3 = 0;
                         const int y3 = (st_up == 2) ? 9 : 8;
-                        for (int c = 0; c < 9; c++) r3 += cnt[c] * dna_score_cls(c, y3);
-                        r3 += nd * 3;                     // score('-','-')
-                        r3 += sc_up;
-                        if (r1 >= r2 && r1 >= r3) { sc_new = r1; st_new = (c0 == '-') ? 1 : 0; d.moves[i * 64 + j] = 0; }
-                        else if (r2 >= r1 && r2 >= r3) { sc_new = r2; st_new = 1; d.moves[i * 64 + j] = 1; }
-                        else { sc_new = r3; st_new = (c0 == '-') ? 0 : 2; d.moves[i * 64 + j] = 2; }
+#pragma unroll
+                        for (int c = 0; c < 9; c++) {
+                            const int k = cnt[c];
+                            r1 += k * scb[c];             // diagonal: cell (i-1, j-1)
+                            r3 += k * dna_score_cls(c, y3);   // delete: cell (i-1, j)
+                        }
+                        r1 += nd * (st_left_prev == 1 ? sb_minus : sb_plus) + sc_left_prev;
+                        r3 += nd * 3 + sc_up;             // score('-','-')
+                        const int r2 = s * (st_l == 1 ? sb_minus : sb_plus) + sc_l;   // insert: cell (i, j-1)
+                        unsigned char mv;
+                        if (r1 >= r2 && r1 >= r3) { sc_new = r1; st_new = (c0 == '-') ? 1 : 0; mv = 0; }
+                        else if (r2 >= r1 && r2 >= r3) { sc_new = r2; st_new = 1; mv = 1; }
+                        else { sc_new = r3; st_new = (c0 == '-') ? 0 : 2; mv = 2; }
+                        s_mv[i * 64 + j] = mv;
                     }
                 }
                 // what lane j-1 held BEFORE this step is cell (i-1, j-1) for the next step
@@ -1044,34 +1060,37 @@ __global__ __launch_bounds__(256) void k_msa(MsaDev d) {
             int r1 = ncol - 1, r2 = len - 1;
             while (!(x == 0 && y == 0)) {
                 int mv;
-                if (x == 0) mv = 1; else if (y == 0) mv = 2; else mv = d.moves[x * 64 + y];
-                if (mv == 0) { d.trace[2 * cnt] = r1; d.trace[2 * cnt + 1] = r2; --r1; --r2; --x; --y; }
-                else if (mv == 1) { d.trace[2 * cnt] = -1; d.trace[2 * cnt + 1] = r2; --r2; --y; }
-                else { d.trace[2 * cnt] = r1; d.trace[2 * cnt + 1] = -1; --r1; --x; }
+                if (x == 0) mv = 1; else if (y == 0) mv = 2; else mv = s_mv[x * 64 + y];
+                if (mv == 0) { s_trace[2 * cnt] = r1; s_trace[2 * cnt + 1] = r2; --r1; --r2; --x; --y; }
+                else if (mv == 1) { s_trace[2 * cnt] = -1; s_trace[2 * cnt + 1] = r2; --r2; --y; }
+                else { s_trace[2 * cnt] = r1; s_trace[2 * cnt + 1] = -1; --r1; --x; }
                 cnt++;
             }
             s_newn = cnt;
         }
         __syncthreads();
-        // ---- rebuild columns (reversed traceback order) and their counts
+        // ---- rebuild columns (reversed traceback order); counts follow incrementally
         const int newn = s_newn;
         char* coln = d.cols[cur ^ 1];
+        unsigned short* cntn = s_cnt + (cur ^ 1) * MSA_CM * 10;
+        char* c0n = s_c0 + (cur ^ 1) * MSA_CM;
         for (long idx = tid; idx < (long)newn * (s + 1); idx += nt) {
             const int c = (int)(idx / (s + 1)), k = (int)(idx % (s + 1));
-            const int src = d.trace[2 * (newn - 1 - c)], sj = d.trace[2 * (newn - 1 - c) + 1];
+            const int src = s_trace[2 * (newn - 1 - c)], sj = s_trace[2 * (newn - 1 - c) + 1];
             char ch;
             if (k < s) ch = (src >= 0) ? colc[(long)src * n + k] : '-';
             else ch = (sj >= 0) ? seq[sj] : '-';
             coln[(long)c * n + k] = ch;
         }
-        __syncthreads();
-        for (int idx = tid; idx < newn * 11; idx += nt) d.counts[idx] = 0;
-        __syncthreads();
         for (int c = tid; c < newn; c += nt) {
-            int loc[11];
-            for (int k = 0; k < 11; k++) loc[k] = 0;
-            for (int k = 0; k <= s; k++) loc[cls_of(coln[(long)c * n + k])]++;
-            for (int k = 0; k < 11; k++) d.counts[c * 11 + k] = loc[k];
+            const int src = s_trace[2 * (newn - 1 - c)], sj = s_trace[2 * (newn - 1 - c) + 1];
+            const int cl = cls_of((sj >= 0) ? seq[sj] : '-');
+            for (int k = 0; k < 10; k++) {
+                int v = (src >= 0) ? (int)cntc[src * 10 + k] : (k == 9 ? s : 0);
+                if (k == cl) v += 1;
+                cntn[c * 10 + k] = (unsigned short)v;
+            }
+            c0n[c] = (src >= 0) ? c0c[src] : '-';
         }
         if (tid == 0) s_ncol = newn;
         cur ^= 1;
@@ -1221,6 +1240,7 @@ template <int V, bool L> static int set_chain_attr() {
 }
 int init_kernels() {
     int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEVEL_LDS);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msa), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSA_LDS);
     rc |= set_chain_attr<0, true>(); rc |= set_chain_attr<0, false>();
     rc |= set_chain_attr<1, true>(); rc |= set_chain_attr<1, false>();
     rc |= set_chain_attr<2, true>(); rc |= set_chain_attr<2, false>();
@@ -1245,7 +1265,7 @@ void launch_chain(hipStream_t st, const JobDev& job, const LevelParams* P, Level
     }
 #undef SC_CHAIN
 }
-void launch_msa(hipStream_t st, const MsaDev& d) { hipLaunchKernelGGL(k_msa, dim3(1), dim3(256), 0, st, d); }
+void launch_msa(hipStream_t st, const MsaDev& d) { hipLaunchKernelGGL(k_msa, dim3(1), dim3(256), MSA_LDS, st, d); }
 // a5 in four launches; `pool_sorted` receives the class pools in read order.
 void launch_thread(hipStream_t st, const ThreadDev& d, int* pool_sorted) {
     const int ncls = d.glen * 8;

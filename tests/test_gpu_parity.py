@@ -218,3 +218,40 @@ def test_thread_kernels_class_tables(seed, tmp_path):
                     assert first[cls] == members[0]
                 off += cnt[cls]
             assert off == len(pool)
+
+
+def test_msa_kernel_deep_and_long(oracle_bin):
+    """k_msa with hundreds of rows (deep coverage at an indel hot spot) and with insertions up to
+    the 63-base limit of the one-wavefront DP."""
+    import time
+    from rambl_amd import capi
+    rng = random.Random(17)
+    with capi.Context(0, 1) as ctx:
+        # an indel hot spot at depth 600: three insertion alleles plus sequencing errors
+        alleles = ["ACGTTGCA", "ACGTA", "GT"]
+
+        def noisy(a):
+            out = []
+            for ch in a:
+                r = rng.random()
+                if r < 0.03:
+                    continue
+                out.append(rng.choice("ACGT") if r < 0.06 else ch)
+                if rng.random() < 0.02:
+                    out.append(rng.choice("ACGT"))
+            return "".join(out) or "A"
+        seqs = [noisy(rng.choice(alleles)) for _ in range(600)]
+        seqs.sort(key=len, reverse=True)
+        t0 = time.time()
+        got = ctx.msa_align(seqs)
+        t_gpu = time.time() - t0
+        t0 = time.time()
+        exp = T.oracle_msa(seqs)
+        t_cpu = time.time() - t0
+        assert got == exp
+        print("msa 600 rows: gpu %.3f s, oracle %.3f s" % (t_gpu, t_cpu))
+        seqs = ["".join(rng.choice("ACGT") for _ in range(rng.choice([63, 40, 17, 5, 2]))) for _ in range(12)]
+        seqs.sort(key=len, reverse=True)
+        assert ctx.msa_align(seqs) == T.oracle_msa(seqs)
+        with pytest.raises(capi.StrainCallError):
+            ctx.msa_align(["A" * 10, "C" * 64])       # second sequence longer than 63: reported, not guessed
