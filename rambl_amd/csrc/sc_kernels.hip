@@ -746,7 +746,43 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
             const bool fresh = job.ent_first[e] && !job.has[rid];
             *cell = fresh ? val : (*cell + val);            // Strain::update_read_loglik, Strain.cpp:85-95
         };
-        if (!P->has_dups) {
+        if (!P->has_dups && !P->any_multi) {
+            // single-symbol labels everywhere (the usual level): four items per thread in flight,
+            // so the dependent loads entry -> read id -> log-likelihood cell overlap
+            const long total = (long)S * Rn;
+            constexpr int U = 4;
+            for (long base = tid; base < total; base += (long)U * nt) {
+                int sidx[U], rid[U], bsym[U];
+                bool live[U], fresh[U];
+                double* cell[U];
+                double old[U];
+#pragma unroll
+                for (int k = 0; k < U; k++) {
+                    const long idx = base + (long)k * nt;
+                    live[k] = idx < total;
+                    const long ii = live[k] ? idx : 0;
+                    sidx[k] = (int)(ii / Rn);
+                    const int e = e0 + (int)(ii % Rn);
+                    rid[k] = job.ent_rid[e];
+                    bsym[k] = job.labels[job.ent_lab_off[e]];
+                    fresh[k] = job.ent_first[e] != 0;
+                }
+#pragma unroll
+                for (int k = 0; k < U; k++) {
+                    cell[k] = job.ll + (long)s_slot[sidx[k]] * stride + rid[k];
+                    fresh[k] = fresh[k] && !job.has[rid[k]];
+                    old[k] = *cell[k];
+                }
+#pragma unroll
+                for (int k = 0; k < U; k++) {
+                    int a = job.labels[s_laboff[sidx[k]]];
+                    const int b = bsym[k];
+                    if (a == codeN) a = b;
+                    const double val = (a < K && b < K) ? s_tab[sidx[k] * KK + a * KMAX + b] : __longlong_as_double(0x7ff8000000000000ll);
+                    if (live[k]) *cell[k] = fresh[k] ? val : (old[k] + val);       // Strain::update_read_loglik, Strain.cpp:85-95
+                }
+            }
+        } else if (!P->has_dups) {
             const long total = (long)S * Rn;
             for (long idx = tid; idx < total; idx += nt) item((int)(idx / Rn), (int)(idx % Rn));
         } else {
@@ -854,13 +890,31 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
 
     // ---- MODE_SAMPLE: the per-slot log-likelihood table; k_chain draws from it
     if (P->n_sweeps <= 0 || S == 1) return;           // nothing to draw (host handles S == 1 and n == 0)
-    for (long idx = tid; idx < (long)S * Q; idx += nt) {
-        const int s = (int)(idx / Q), q = (int)(idx % Q);
-        const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
-        const double* row = job.ll + (long)s_slot[s] * stride;
-        double x = job.has[rid] ? row[rid] : 0.0;
-        if (uid >= 0 && job.has[uid]) x += row[uid];
-        job.tabA[(long)s * job.qcap + q] = x;
+    {
+        const long total = (long)S * Q;
+        constexpr int U = 4;
+        for (long base = tid; base < total; base += (long)U * nt) {
+            int sidx[U], qq[U], rid[U], uid[U];
+            bool live[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const long idx = base + (long)k * nt;
+                live[k] = idx < total;
+                const long ii = live[k] ? idx : 0;
+                sidx[k] = (int)(ii / Q); qq[k] = (int)(ii % Q);
+                rid[k] = job.ent_rid[e0 + job.qent[qq[k]]];
+                uid[k] = job.quid[qq[k]];
+            }
+            double x[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const double* row = job.ll + (long)s_slot[sidx[k]] * stride;
+                x[k] = job.has[rid[k]] ? row[rid[k]] : 0.0;
+                if (uid[k] >= 0 && job.has[uid[k]]) x[k] += row[uid[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) if (live[k]) job.tabA[(long)sidx[k] * job.qcap + qq[k]] = x[k];
+        }
     }
 }
 

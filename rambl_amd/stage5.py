@@ -183,3 +183,45 @@ def strain_call(fasta, bam, out_dir=None, prefix="rambl", opts=None, device=0, s
         with open(os.path.join(out_dir, "%s.fa" % prefix), "w") as f:
             f.write(full)
     return full
+
+
+def main(argv=None):
+    """`python -m rambl_amd.stage5 seed_otus.fasta to_seed_otus.all.bam -o WORKDIR -p PREFIX`
+    (under `torchrun --nproc-per-node N` for N GPUs): stage 5 of rambl.py + the length filter."""
+    import argparse
+    ap = argparse.ArgumentParser(description="rambl.py stage 5 (strain-level assembly) on MI355X")
+    ap.add_argument("fasta")
+    ap.add_argument("alignments", help="BAM or SAM text of the reads aligned to the seed genes")
+    ap.add_argument("-o", "--out-dir", default=".")
+    ap.add_argument("-p", "--prefix", default="rambl")
+    ap.add_argument("-s", "--streams", type=int, default=8, help="regions in flight per GPU")
+    for k, v in RAMBL_DEFAULTS.items():
+        ap.add_argument("--" + k.replace("_", "-"), default=v, type=type(v))
+    a = ap.parse_args(argv)
+    opts = {k: getattr(a, k) for k in RAMBL_DEFAULTS}
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = dev = None
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.streams > 4:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(a.streams, 24)))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=int(os.environ["RANK"]), world_size=world)
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    full = strain_call(a.fasta, a.alignments, out_dir=a.out_dir, prefix=a.prefix, opts=opts, device=local,
+                       streams=a.streams, dist=dist, torch_device=dev)
+    if full is not None:
+        with open(os.path.join(a.out_dir, "%s.filtered.fa" % a.prefix), "w") as f:
+            f.write(seqtk_L(full, 400))            # rambl.py:236-238
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(main())
