@@ -43,6 +43,7 @@ struct JobDev {
     uint8_t* qcode;              // [qcap] read-label symbol code of a draw slot (0xFF: not a single symbol)
     int* qent;                   // [qcap] entry index of a draw slot
     int* quid;                   // [qcap] mate read id of a draw slot (-1 none)
+    uint8_t* rec;                // [MAX_DRAWS + 64] strain chosen by each draw of the current sampler launch
     long qcap;
 };
 
