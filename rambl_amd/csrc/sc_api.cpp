@@ -148,6 +148,7 @@ struct Ctx {
     bool stop = false;
     std::vector<std::unique_ptr<Worker>> workers;
     double* dU = nullptr;             // uniform stream on the device
+    float* dUf = nullptr;             // fp32 copy
 };
 
 struct Worker {
@@ -360,6 +361,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     jd.has = (uint8_t*)b_has.ensure((size_t)n_reads + 8);
     HIPCHK(hipMemsetAsync(jd.has, 0, (size_t)n_reads + 8, st));
     jd.U = ctx->dU;
+    jd.Uf = ctx->dUf;
     jd.isnew = (uint8_t*)b_isnew.ensure((size_t)max_level_entries + 8);
     jd.qcap = qcap;
     jd.tabA = (double*)b_tabA.ensure(sizeof(double) * (size_t)qcap * MAXS);
@@ -495,9 +497,10 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         if (timed) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
-            if (level_log) fprintf(level_log, "S %d Q %d n %d ms %.4f redo %llu slow %llu cyc %llu redocyc %llu\n", S, Q, n_sweeps, ms,
-                                   (unsigned long long)Rh->n_redo, (unsigned long long)Rh->n_slow,
-                                   (unsigned long long)Rh->chain_cycles, (unsigned long long)Rh->redo_cycles);
+            if (level_log) fprintf(level_log, "S %d Q %d n %d ms %.4f redo %llu careful %llu slow %llu cyc %llu redocyc %llu ph %llu %llu %llu\n", S, Q, n_sweeps, ms,
+                                   (unsigned long long)Rh->n_redo, (unsigned long long)Rh->n_careful, (unsigned long long)Rh->n_slow,
+                                   (unsigned long long)Rh->chain_cycles, (unsigned long long)Rh->redo_cycles,
+                                   (unsigned long long)Rh->phase[0], (unsigned long long)Rh->phase[1], (unsigned long long)Rh->phase[2]);
             sampler_ms += ms;
         }
     };
@@ -809,6 +812,12 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         delete h;
         return SC_ERR_HIP;
     }
+    std::vector<float> uf(u.begin(), u.end());
+    if (hipMalloc((void**)&ctx->dUf, sizeof(float) * uf.size()) != hipSuccess ||
+        hipMemcpy(ctx->dUf, uf.data(), sizeof(float) * uf.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        delete h;
+        return SC_ERR_HIP;
+    }
     if (stream_count < 1) stream_count = 1;
     if (stream_count > 64) stream_count = 64;
     for (int i = 0; i < stream_count; i++) {
@@ -838,6 +847,7 @@ void sc_ctx_destroy(sc_ctx* h) {
     }
     ctx->workers.clear();
     if (ctx->dU) (void)hipFree(ctx->dU);
+    if (ctx->dUf) (void)hipFree(ctx->dUf);
     delete h;
 }
 

@@ -34,6 +34,7 @@ struct JobDev {
     long ll_stride;
     uint8_t* has;                // read present in read_loglik (identical for every strain)
     const double* U;             // generate_canonical<double,53>(mt19937(1234)) stream, MAX_DRAWS values
+    const float* Uf;             // the same stream rounded to fp32 (first tier of the sampler)
     // scratch
     uint8_t* isnew;              // [max entries per level]
     double* tabA;                // [MAXS][qcap]  LLq / P  (strain-major)
@@ -78,6 +79,7 @@ struct LevelResult {
     unsigned long long redo_cycles;  // shader cycles spent replaying flagged blocks
     unsigned long long chain_cycles, chain_wall;   // shader cycles / 100 MHz ticks spent in the urn chain
     unsigned long long n_exact;  // draws resolved by the literal fp64 path
+    unsigned long long phase[4]; // diagnostics (SC_PHASE_TIMING builds): shader cycles per phase of the wide chain
     int error;
 };
 

@@ -669,39 +669,62 @@ __device__ __forceinline__ void urn_chain_g4(const JobDev& job, const LevelParam
 }
 
 // --------------------------------------------------------------------------
-// Wide urn chain: one draw per lane, 64 draws per batch.
+// Wide urn chain: one draw per lane, a sliding window of 64 draws.
 //
-// Lane j of a batch evaluates draw t0+j on its own: it walks the strains in order
-// with the counts k of the START of the batch (uniform over the lanes), so that
-// cum_s = sum_{s'<=s} (a0_s' + k_s') * L[q_j][s'] costs one FMA per strain and no
-// cross-lane traffic.  The j draws in front of it can move any cum_s - u*T by at
-// most j (every L <= 1 and each draw adds one to one count), so the decision of
-// lane j is FINAL whenever no boundary lies within (eps*T + j) of u*T -- whatever
-// the earlier draws of the batch turn out to be.  Lanes that pass the test commit
-// together (one LDS float atomic per lane); a lane that fails is resolved in
-// order: the lanes before it commit, then the wave evaluates that one draw with
-// the exact counts through the checked tiers (fp32 scan + two ballots, fp64 scan,
-// literal).  eps bounds the fp32 error of the sequential FMA chain,
-// (2*S + 9) * 2^-24 relative to T.
+// Lane j of a pass evaluates draw t+j on its own: it walks the strains in order
+// with the counts k as they are in front of draw t (uniform over the lanes), so
+// that cum_s = sum_{s'<=s} (a0_s' + k_s') * L[q_j][s'] costs one FMA per strain
+// and no cross-lane traffic.  The j draws in front of it can move any
+// cum_s - u*T by at most j (every L <= 1 and each draw adds one to one count), so
+// the decision of lane j is FINAL whenever no boundary lies within (eps*T + j) of
+// u*T -- whatever the earlier draws of the window turn out to be.  Each pass
+// accepts the lanes in front of the first one that fails this test (one LDS float
+// atomic per accepted lane) and the window moves on to that draw, which then sits
+// in lane 0 with margin eps*T only.  A draw that fails in lane 0 is within the
+// fp32 error bound of a boundary (or its slot is flagged): it goes through the
+// fp64 scan and, if needed, the literal evaluation.  eps bounds the fp32 error of
+// the FMA chains, < (2*S + 9) * 2^-24 relative to T.
 //
+// Strains are handled in blocks of 16 (NB blocks, compile time; padding has
+// weight 0): block-local chains, block offsets folded into the comparison value.
 // Weight rows are row-major [Q][stride], stride = 4 * odd, so that the 16-byte
 // reads of 64 lanes (consecutive rows) spread over all LDS banks.
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 
-template <int SP, bool ROWS_LDS>
+__device__ __forceinline__ float fma_rn(float a, float b, float c) {       // three-address FMA (no v_fmac + copy)
+    float d;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f2v pk_sub(f2v a, f2v b) {
+    f2v d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float min3_abs(float m, float x, float y) {
+    float d;
+    asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(d) : "v"(m), "v"(x), "v"(y));
+    return d;
+}
+
+constexpr int UWIN = 1024;     // uniforms staged in LDS (fp32), refilled in halves
+
+template <int NB, bool ROWS_LDS>
 __device__ __forceinline__ void urn_chain_w(const JobDev& job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
                                             const int* s_slot, volatile double* s_a, volatile double* s_p, float* s_kf,
-                                            const float* s_a0f, const float* rows_lds, int stride, int lane) {
-    constexpr int NG = SP / 4;                             // groups of four strains
+                                            const float* s_a0f, float* s_uwin, const float* rows_lds, int stride, int lane) {
+    constexpr int SP = 16 * NB, NG = 4 * NB;
     constexpr int NPLC = SP > 64 ? 2 : 1;                  // strains per lane in the checked tier
     constexpr float EPSW = (float)(SP + 12) * 1.5e-7f;
     constexpr float BIG = 1.0e30f;
-    constexpr bool A0REG = SP <= 64;
+    constexpr bool A0REG = NB <= 4;
     const int S = P->S, Q = P->Q, n = P->n_sweeps, e0 = P->e0;
     const int Sm1 = S - 1;
     const int total = n * Q;
     const SlowArgs sa{job.tabA, job.qmax, job.qcap, job.qflag, job.qent, job.quid, job.ent_rid, job.ll, job.ll_stride, job.has};
     const SC_GLOBAL double* Ustream = (const SC_GLOBAL double*)job.U;
+    const SC_GLOBAL float* Uf = (const SC_GLOBAL float*)job.Uf;
     const SC_GLOBAL float* rows_g = (const SC_GLOBAL float*)job.tabLf;
     SC_GLOBAL uint8_t* rec = (SC_GLOBAL uint8_t*)job.rec;
     auto ld4 = [&](int idx) __attribute__((always_inline)) -> f4v {
@@ -710,181 +733,152 @@ __device__ __forceinline__ void urn_chain_w(const JobDev& job, const LevelParams
     auto ld1 = [&](int idx) __attribute__((always_inline)) -> float { return ROWS_LDS ? rows_lds[idx] : rows_g[idx]; };
 
     double a0m[NPLC];
-    float a0mf[NPLC];
 #pragma unroll
-    for (int i = 0; i < NPLC; i++) {
-        const int s = lane * NPLC + i;
-        a0m[i] = (s < S) ? P->a0[s] : 0.0;
-        a0mf[i] = (float)a0m[i];
-    }
+    for (int i = 0; i < NPLC; i++) { const int s = lane * NPLC + i; a0m[i] = (s < S) ? P->a0[s] : 0.0; }
     f4v a0u[A0REG ? NG : 1];
     if (A0REG) {
 #pragma unroll
         for (int g = 0; g < NG; g++) a0u[A0REG ? g : 0] = *(const f4v*)(s_a0f + 4 * g);
     }
-    unsigned long long n_exact = 0, n_slow = 0, n_fail = 0, n_failbatch = 0, fail_cycles = 0;
+    unsigned long long n_exact = 0, n_slow = 0, n_pass = 0;
     const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
 
-    // one draw with the exact current counts (s_kf), strains across the lanes
-    auto checked_draw = [&](int qi, double u) __attribute__((always_inline)) -> int {
-        const float uf = (float)u;
-        float w[NPLC], pair = 0.0f;
-        double ad[NPLC];
+    // uniforms: draws [ulo, ulo + UWIN) live in s_uwin[p & (UWIN-1)]
+    int ulo = 0;
+    bool upf = false;
+    f4v ux0 = 0.0f, ux1 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < NPLC; i++) {
-            const int s = lane * NPLC + i;
-            const float kk = (s < S) ? s_kf[s] : 0.0f;
-            const float L = (s < S) ? ld1(qi * stride + s) : 0.0f;
-            ad[i] = a0m[i] + (double)kk;
-            w[i] = (a0mf[i] + kk) * L;
-            pair += w[i];
-        }
-        const float incl = wave_scan_incl_f32(pair);
-        const float T = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
-        const float tgt = uf * T, mg = DRAW_EPS32 * T;
-        const float lo = tgt - mg, hi = tgt + mg;
-        bool fast = (T > 0.0f) && (T < 1.0e30f);
-        int c;
-        if (NPLC == 1) {
-            const unsigned long long mlo = __ballot(incl >= lo), mhi = __ballot(incl >= hi);
-            fast = fast && (mlo == mhi) && (mlo != 0ull);
-            c = (int)__builtin_ctzll(mlo | (1ull << 63));
-        } else {
-            const float E = dpp_f32<0x138, 0xF, 0xF, true>(incl);   // wave_shr:1
-            const float c0 = E + w[0], c1 = E + pair;
-            const unsigned long long m0lo = __ballot(c0 >= lo), m0hi = __ballot(c0 >= hi);
-            const unsigned long long m1lo = __ballot(c1 >= lo), m1hi = __ballot(c1 >= hi);
-            fast = fast && (m0lo == m0hi) && (m1lo == m1hi) && (m1lo != 0ull);
-            const int l1 = (int)__builtin_ctzll(m1lo | (1ull << 63));
-            c = 2 * l1 + (((m0lo >> l1) & 1ull) ? 0 : 1);
-        }
-        if (!fast) {
-            c = slow_draw<NPLC>(sa, s_slot, s_a, s_p, ad[0], NPLC > 1 ? ad[NPLC - 1] : 0.0, S, qi, e0, u, lane);
-            n_slow++;
-            n_exact += (c >> 8) & 1;
-            c &= 0xFF;
-        }
-        return c;
-    };
+    for (int k = 0; k < UWIN / 256; k++) *(f4v*)(s_uwin + 256 * k + 4 * lane) = *(const SC_GLOBAL f4v*)(Uf + 256 * k + 4 * lane);
 
+    constexpr int NSB = 2 * NB;                            // sub-blocks of eight strains: independent FMA chains
+    int t = 0;
+    int ro = (lane % Q) * stride;                          // row offset (floats) of this lane's draw
+    const int wrap = Q * stride;
+    int upos = lane;                                       // (t + lane) & (UWIN - 1)
+    const float lanef = (float)lane + 1.0e-37f;
     f4v L[NG];
-    auto load_rows = [&](int q) __attribute__((always_inline)) {
-        const int ro = q * stride;
+    float uf = 0.0f, llast = 0.0f;
+    auto issue_loads = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int b = 0; b < NG / 4; b++) {
-            if (16 * b < S) {
-#pragma unroll
-                for (int g = 4 * b; g < 4 * b + 4; g++) L[g] = ld4(ro + 4 * g);
-            }
-        }
+        for (int g = 0; g < NG; g++) L[g] = ld4(ro + 4 * g);
+        llast = ld1(ro + Sm1);
+        uf = s_uwin[upos];
     };
-    int ql = lane % Q;
-    const int step = 64 % Q;
-    double u_cur = Ustream[lane];                           // the stream is padded past MAX_DRAWS
-    if (total > 0) load_rows(ql);
+    __builtin_amdgcn_wave_barrier();
+    if (total > 0) issue_loads();
 #pragma unroll 1
-    for (int t0 = 0; t0 < total; t0 += 64) {
-        const bool active = t0 + lane < total;
+    while (t < total) {
         asm volatile("" ::: "memory");                      // s_kf below must be re-read
-        // pass 1: cumulative weights with the counts of the start of the batch
-        f4v cum[NG];
-        float run = 0.0f;
+        n_pass++;
+        // pass 1: sub-block-local cumulative weights with the counts in front of draw t
+        f4v av[NG];
 #pragma unroll
-        for (int b = 0; b < NG / 4; b++) {
-            if (16 * b < S) {
+        for (int g = 0; g < NG; g++)
+            av[g] = (A0REG ? a0u[A0REG ? g : 0] : *(const f4v*)(s_a0f + 4 * g)) + *(const f4v*)(s_kf + 4 * g);
+        const float alast = s_a0f[Sm1] + s_kf[Sm1];
+        float loc[SP], run[NSB];
 #pragma unroll
-                for (int g = 4 * b; g < 4 * b + 4; g++) {
-                    const f4v k = *(const f4v*)(s_kf + 4 * g);
-                    const f4v a = (A0REG ? a0u[A0REG ? g : 0] : *(const f4v*)(s_a0f + 4 * g)) + k;
-                    f4v cg;
-                    cg.x = run = fmaf(a.x, L[g].x, run);
-                    cg.y = run = fmaf(a.y, L[g].y, run);
-                    cg.z = run = fmaf(a.z, L[g].z, run);
-                    cg.w = run = fmaf(a.w, L[g].w, run);
-                    cum[g] = cg;
-                }
+        for (int j = 0; j < 8; j++) {
+#pragma unroll
+            for (int sb = 0; sb < NSB; sb++) {
+                const int sidx = 8 * sb + j;
+                const float aa = av[sidx >> 2][sidx & 3], ll = L[sidx >> 2][sidx & 3];
+                run[sb] = (j == 0) ? aa * ll : fma_rn(aa, ll, run[sb]);
+                loc[sidx] = run[sb];
             }
         }
-        const float T = run;
-        // the weight of the last strain, for the distance to the boundary below it
-        const float wlast = (s_a0f[Sm1] + s_kf[Sm1]) * ld1(ql * stride + Sm1);
-        const double u_d = u_cur;
-        const float uf = (float)u_d;
-        // operands of the next batch
-        int qn = ql + step;
-        qn -= (qn >= Q) ? Q : 0;
-        if (t0 + 64 < total) load_rows(qn);
-        u_cur = Ustream[t0 + 64 + lane];
+        float off[NSB + 1];
+        off[0] = 0.0f;
+#pragma unroll
+        for (int sb = 0; sb < NSB; sb++) off[sb + 1] = off[sb] + run[sb];
+        const float T = off[NSB];
         // pass 2: position of u*T among the boundaries and the distance to the nearest one
         const float tgt = uf * T;
-        unsigned bits[(SP + 31) / 32];
+        f2v tb2[NSB];
 #pragma unroll
-        for (int i = 0; i < (SP + 31) / 32; i++) bits[i] = 0;
-        float dmin = BIG;
+        for (int sb = 0; sb < NSB; sb++) { const float tb = tgt - off[sb]; tb2[sb] = f2v{tb, tb}; }
+        unsigned w[NSB];
+        float dm0 = BIG, dm1 = BIG;
 #pragma unroll
-        for (int b = 0; b < NG / 4; b++) {
-            if (16 * b < Sm1) {
+        for (int j = 0; j < 8; j += 2) {
 #pragma unroll
-                for (int g = 4 * b; g < 4 * b + 4; g++) {
-                    const f4v d = cum[g] - tgt;
-                    unsigned w = bits[g / 8];
-                    w = __builtin_amdgcn_alignbit(w, __float_as_uint(d.x), 31);   // (w << 1) | sign(d)
-                    w = __builtin_amdgcn_alignbit(w, __float_as_uint(d.y), 31);
-                    w = __builtin_amdgcn_alignbit(w, __float_as_uint(d.z), 31);
-                    w = __builtin_amdgcn_alignbit(w, __float_as_uint(d.w), 31);
-                    bits[g / 8] = w;
-                    dmin = fminf(dmin, fminf(fabsf(d.x), fabsf(d.y)));
-                    dmin = fminf(dmin, fminf(fabsf(d.z), fabsf(d.w)));
-                }
+            for (int sb = 0; sb < NSB; sb++) {
+                const f2v lc = {loc[8 * sb + j], loc[8 * sb + j + 1]};
+                const f2v d = pk_sub(lc, tb2[sb]);
+                w[sb] = __builtin_amdgcn_alignbit(j == 0 ? 0u : w[sb], __float_as_uint(d.x), 31);   // (w << 1) | sign(d)
+                w[sb] = __builtin_amdgcn_alignbit(w[sb], __float_as_uint(d.y), 31);
+                if (sb & 1) dm1 = min3_abs(dm1, d.x, d.y); else dm0 = min3_abs(dm0, d.x, d.y);
             }
         }
         int c = 0;
 #pragma unroll
-        for (int i = 0; i < (SP + 31) / 32; i++) c += __popc(bits[i]);
-        // Strains >= S-1 (and the padding) all sit at cum = T >= u*T: they never count, and their
-        // distance T - u*T only matters when every real boundary is below u*T (c == S-1); then the
-        // nearest real boundary is the one under the last strain.
-        if (c == Sm1) dmin = tgt - (T - wlast);
-        bool ok = !active || ((dmin >= fmaf(EPSW, T, (float)lane)) && (T > 0.0f) && (T < 1.0e30f));
-        if (S < 2) { ok = true; c = 0; }
-
-        unsigned long long F = __ballot(!ok);
-        bool pending = active;
-        if (F == 0ull) {
-            if (pending) __hip_atomic_fetch_add(&s_kf[c], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            const unsigned long long f0 = clock64();
-            n_failbatch++;
-            while (true) {
-                const int i = F ? (int)__builtin_ctzll(F) : 64;
-                if (pending && lane < i) __hip_atomic_fetch_add(&s_kf[c], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                pending = pending && (lane > i);
-                if (i == 64) break;
-                asm volatile("" ::: "memory");
-                const int qi = __builtin_amdgcn_readlane(ql, i);
-                const double ui = readlane_f64(u_d, i);
-                const int ci = checked_draw(qi, ui);
-                if (lane == i) c = ci;
-                if (lane == 0) __hip_atomic_fetch_add(&s_kf[ci], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                asm volatile("" ::: "memory");
-                n_fail++;
-                F &= F - 1ull;
-            }
-            fail_cycles += clock64() - f0;
+        for (int sb = 0; sb < NSB; sb++) c += __popc(w[sb]);
+        // Strains >= S-1 and the padding all sit at cum = T >= u*T.  They never count (a padding entry
+        // can round to a tiny negative difference: the count is clamped), and their distance T - u*T
+        // must not enter the margin test: alt = -(cum_{S-2} - u*T) is <= 0 while a real boundary lies
+        // at or above u*T and is the distance to the nearest real boundary when none does.
+        c = min(c, Sm1);
+        const float alt = tgt - (T - alast * llast);
+        const float dmin = fmaxf(fminf(dm0, dm1), alt);
+        const float lim = fmaf(EPSW, T, lanef);             // NaN (flagged slot) and T == 0 fail the test
+        const unsigned long long F = ~__ballot(dmin >= lim);
+        const int rem = total - t;
+        int adv = F ? (int)__builtin_ctzll(F) : 64;
+        adv = adv < rem ? adv : rem;
+        if (adv == 0) {
+            // draw t itself: fp64 scan with the exact counts, then the literal tier
+            const double u = Ustream[t];
+            double ad[NPLC];
+#pragma unroll
+            for (int i = 0; i < NPLC; i++) { const int s = lane * NPLC + i; ad[i] = a0m[i] + (double)((s < S) ? s_kf[s] : 0.0f); }
+            const int qi = __builtin_amdgcn_readfirstlane(ro) / stride;
+            int cc = slow_draw<NPLC>(sa, s_slot, s_a, s_p, ad[0], NPLC > 1 ? ad[NPLC - 1] : 0.0, S, qi, e0, u, lane);
+            n_slow++;
+            n_exact += (cc >> 8) & 1;
+            c = cc & 0xFF;
+            adv = 1;
         }
-        if (active) rec[t0 + lane] = (uint8_t)c;
-        ql = qn;
+        const bool acc = lane < adv;
+        if (acc) rec[t + lane] = (uint8_t)c;
+        t += adv;
+        if (t >= total) {
+            if (acc) __hip_atomic_fetch_add(&s_kf[c], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
+        if (Q >= 64) {
+            const unsigned r1 = (unsigned)(ro + adv * stride);
+            const unsigned r2 = r1 - (unsigned)wrap;         // wraps to a huge value while r1 < wrap
+            ro = (int)(r1 < r2 ? r1 : r2);
+        } else {
+            ro = ((ro / stride + adv) % Q) * stride;
+        }
+        upos = (upos + adv) & (UWIN - 1);
+        // uniforms: prefetch the next half window, swap it in when the window has moved past the old one
+        if (!upf && t >= ulo + UWIN / 4) {
+            ux0 = *(const SC_GLOBAL f4v*)(Uf + ulo + UWIN + 4 * lane);
+            ux1 = *(const SC_GLOBAL f4v*)(Uf + ulo + UWIN + 256 + 4 * lane);
+            upf = true;
+        }
+        if (t >= ulo + UWIN / 2) {
+            *(f4v*)(s_uwin + ((ulo & (UWIN - 1)) + 4 * lane)) = ux0;
+            *(f4v*)(s_uwin + ((ulo & (UWIN - 1)) + 256 + 4 * lane)) = ux1;
+            ulo += UWIN / 2;
+            upf = false;
+        }
+        issue_loads();                                       // rows of the new window first, then the commit, then the counts
+        if (acc) __hip_atomic_fetch_add(&s_kf[c], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < NPLC; i++) {
         const int s = lane * NPLC + i;
         if (s < S) R->abund[s] = a0m[i] + (double)s_kf[s];
     }
     if (lane == 0) {
-        R->n_draws = (unsigned long long)total; R->n_exact = n_exact; R->n_slow = n_slow; R->n_redo = n_failbatch;
-        R->n_careful = n_fail;
-        R->chain_cycles = clock64() - clk0; R->chain_wall = wall_clock64() - wall0; R->redo_cycles = fail_cycles;
+        R->n_draws = (unsigned long long)total; R->n_exact = n_exact; R->n_slow = n_slow; R->n_redo = n_pass;
+        R->n_careful = n_slow;
+        R->chain_cycles = clock64() - clk0; R->chain_wall = wall_clock64() - wall0; R->redo_cycles = 0;
     }
 }
 
@@ -1207,12 +1201,13 @@ __global__ __launch_bounds__(256) void k_chain(JobDev job, const LevelParams* __
     for (int i = tid; i < S * KMAX; i += nt) R->cnt[i] = s_cnt[i];
 }
 
-// The same stage with the wide chain (urn_chain_w).  SP = register capacity in strains.
+// The same stage with the wide chain (urn_chain_w).  NB = blocks of 16 strains.
 __host__ __device__ inline int chain_w_stride(int S) {
     const int s4 = (S + 3) & ~3;
     return (s4 & 4) ? s4 : s4 + 4;                            // 4 * odd
 }
-template <int SP, bool ROWS_LDS>
+constexpr int CHAINW_ROWS_BYTES = LDS_BIG - UWIN * 4;
+template <int NB, bool ROWS_LDS>
 __global__ __launch_bounds__(256) void k_chain_w(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_a = reinterpret_cast<double*>(s_raw);              // [MAXS]
@@ -1221,7 +1216,8 @@ __global__ __launch_bounds__(256) void k_chain_w(JobDev job, const LevelParams* 
     int* s_slot = reinterpret_cast<int*>(s_cnt + MAXS * KMAX);   // [MAXS]
     float* s_kf = reinterpret_cast<float*>(s_slot + MAXS);       // [MAXS] draws per strain so far
     float* s_a0f = s_kf + MAXS;                                  // [MAXS] fp32 copy of the starting weights
-    float* s_rows = reinterpret_cast<float*>(s_raw + LDS_SMALL);
+    float* s_uwin = reinterpret_cast<float*>(s_raw + LDS_SMALL); // [UWIN]
+    float* s_rows = s_uwin + UWIN;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int S = P->S, Q = P->Q;
     const int stride = chain_w_stride(S);
@@ -1248,10 +1244,16 @@ __global__ __launch_bounds__(256) void k_chain_w(JobDev job, const LevelParams* 
     // lanes read whole 16-strain blocks: keep what follows the last row finite
     for (int i = tid; i < 16; i += nt) { float* Lf = ROWS_LDS ? (s_rows + (long)Q * stride) : (job.tabLf + (long)Q * stride); Lf[i] = 0.0f; }
     __syncthreads();
-    if (tid < 64) urn_chain_w<SP, ROWS_LDS>(job, P, R, s_slot, s_a, s_p, s_kf, s_a0f, s_rows, stride, tid);
+    const int total = P->n_sweeps * Q;
+    if (S < 2) {
+        // a single candidate takes every draw (discrete_distribution with one weight)
+        for (int t = tid; t < total; t += nt) job.rec[t] = 0;
+        if (tid == 0) { R->abund[0] = P->a0[0] + (double)total; R->n_draws = (unsigned long long)total; }
+    } else if (tid < 64) {
+        urn_chain_w<NB, ROWS_LDS>(job, P, R, s_slot, s_a, s_p, s_kf, s_a0f, s_uwin, s_rows, stride, tid);
+    }
     __syncthreads();
     // draws per (strain, read symbol): the substitution counts of :198-206
-    const int total = P->n_sweeps * Q;
     for (int t = tid; t < total; t += nt) {
         const int code = job.qcode[t % Q];
         if (code < KMAX) atomicAdd(&s_cnt[(int)job.rec[t] * KMAX + code], 1u);
@@ -1566,8 +1568,8 @@ constexpr size_t CHAIN_LDS = LDS_TOTAL;
 template <int V, bool L> static int set_chain_attr() {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain<V, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
 }
-template <int SP, bool L> static int set_chain_w_attr() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_w<SP, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
+template <int NB, bool L> static int set_chain_w_attr() {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_w<NB, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
 }
 int init_kernels() {
     int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEVEL_LDS);
@@ -1576,9 +1578,14 @@ int init_kernels() {
     rc |= set_chain_attr<1, true>(); rc |= set_chain_attr<1, false>();
     rc |= set_chain_attr<2, true>(); rc |= set_chain_attr<2, false>();
     rc |= set_chain_attr<4, true>(); rc |= set_chain_attr<4, false>();
-    rc |= set_chain_w_attr<32, true>(); rc |= set_chain_w_attr<32, false>();
-    rc |= set_chain_w_attr<64, true>(); rc |= set_chain_w_attr<64, false>();
-    rc |= set_chain_w_attr<128, true>(); rc |= set_chain_w_attr<128, false>();
+    rc |= set_chain_w_attr<1, true>(); rc |= set_chain_w_attr<1, false>();
+    rc |= set_chain_w_attr<2, true>(); rc |= set_chain_w_attr<2, false>();
+    rc |= set_chain_w_attr<3, true>(); rc |= set_chain_w_attr<3, false>();
+    rc |= set_chain_w_attr<4, true>(); rc |= set_chain_w_attr<4, false>();
+    rc |= set_chain_w_attr<5, true>(); rc |= set_chain_w_attr<5, false>();
+    rc |= set_chain_w_attr<6, true>(); rc |= set_chain_w_attr<6, false>();
+    rc |= set_chain_w_attr<7, true>(); rc |= set_chain_w_attr<7, false>();
+    rc |= set_chain_w_attr<8, true>(); rc |= set_chain_w_attr<8, false>();
     return rc;
 }
 void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int do_update) {
@@ -1588,11 +1595,14 @@ void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, Level
 void launch_chain(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int S, int Q) {
     static const bool old_chain = getenv("SC_CHAIN_OLD") != nullptr;
     if (!old_chain) {
-        const bool wl = ((long)Q * chain_w_stride(S) + 16) * 4 <= (long)LDS_BIG;
-#define SC_CHAINW(SP, L) hipLaunchKernelGGL((k_chain_w<SP, L>), dim3(1), dim3(256), CHAIN_LDS, st, job, P, R)
-        if (S <= 32) { if (wl) SC_CHAINW(32, true); else SC_CHAINW(32, false); }
-        else if (S <= 64) { if (wl) SC_CHAINW(64, true); else SC_CHAINW(64, false); }
-        else { if (wl) SC_CHAINW(128, true); else SC_CHAINW(128, false); }
+        const bool wl = ((long)Q * chain_w_stride(S) + 16) * 4 <= (long)CHAINW_ROWS_BYTES;
+#define SC_CHAINW(NB) case NB: if (wl) hipLaunchKernelGGL((k_chain_w<NB, true>), dim3(1), dim3(256), CHAIN_LDS, st, job, P, R); \
+                               else hipLaunchKernelGGL((k_chain_w<NB, false>), dim3(1), dim3(256), CHAIN_LDS, st, job, P, R); break;
+        switch ((S + 15) / 16) {
+            SC_CHAINW(1) SC_CHAINW(2) SC_CHAINW(3) SC_CHAINW(4) SC_CHAINW(5) SC_CHAINW(6) SC_CHAINW(7)
+            default: if (wl) hipLaunchKernelGGL((k_chain_w<8, true>), dim3(1), dim3(256), CHAIN_LDS, st, job, P, R);
+                     else hipLaunchKernelGGL((k_chain_w<8, false>), dim3(1), dim3(256), CHAIN_LDS, st, job, P, R);
+        }
 #undef SC_CHAINW
         return;
     }
