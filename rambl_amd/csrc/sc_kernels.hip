@@ -29,7 +29,7 @@ constexpr int LDS_BIG = LDS_TOTAL - LDS_SMALL;
 constexpr int LDS_REC = MAX_DRAWS + 64;
 constexpr int LDS_ROWS_FLOATS = (LDS_BIG - LDS_REC) / 4;    // two-strains-per-lane path (S > 64)
 constexpr int LDS_UBUF = 4096;                            // 1024 staged uniforms (S <= 64 path)
-static_assert(LDS_SMALL >= (int)(sizeof(double) * 3 * MAXS + sizeof(unsigned) * MAXS * KMAX + sizeof(int) * 3 * MAXS), "LDS_SMALL");
+static_assert(LDS_SMALL >= (int)(sizeof(double) * 3 * MAXS + sizeof(unsigned) * MAXS * KMAX + sizeof(int) * 3 * MAXS + 64), "LDS_SMALL");
 static_assert(LDS_BIG >= (int)(sizeof(double) * MAXS * KK), "LDS_BIG");
 static_assert(LDS_REC % 4 == 0, "LDS_REC");
 
@@ -669,28 +669,30 @@ __device__ __forceinline__ void urn_chain_g4(const JobDev& job, const LevelParam
 }
 
 // --------------------------------------------------------------------------
-// Wide urn chain: one draw per lane, a sliding window of 64 draws.
+// Wide urn chain: a sliding window of 64 draws over the four wavefronts of the
+// workgroup (one per SIMD), four lanes per draw.
 //
-// Lane j of a pass evaluates draw t+j on its own: it walks the strains in order
-// with the counts k as they are in front of draw t (uniform over the lanes), so
-// that cum_s = sum_{s'<=s} (a0_s' + k_s') * L[q_j][s'] costs one FMA per strain
-// and no cross-lane traffic.  The j draws in front of it can move any
-// cum_s - u*T by at most j (every L <= 1 and each draw adds one to one count), so
-// the decision of lane j is FINAL whenever no boundary lies within (eps*T + j) of
-// u*T -- whatever the earlier draws of the window turn out to be.  Each pass
-// accepts the lanes in front of the first one that fails this test (one LDS float
-// atomic per accepted lane) and the window moves on to that draw, which then sits
-// in lane 0 with margin eps*T only.  A draw that fails in lane 0 is within the
-// fp32 error bound of a boundary (or its slot is flagged): it goes through the
-// fp64 scan and, if needed, the literal evaluation.  eps bounds the fp32 error of
-// the FMA chains, < (2*S + 9) * 2^-24 relative to T.
+// Draw t+p of a pass (p = 0..63) belongs to the quad of lanes 4*(p%16)..+3 of
+// wave p/16; lane k of the quad walks its quarter of the strains in order with
+// the counts as they are in front of draw t (uniform over the draws), one FMA
+// per strain: cum_s = sum_{s'<=s} (a0_s' + k_s') * L[q][s'].  The quarters are
+// joined inside the quad by DPP (totals -> offsets and T, then the number of
+// boundaries below u*T and the distance to the nearest one).  The p draws in
+// front of draw t+p can move any cum_s - u*T by at most p (every L <= 1 and each
+// draw adds one to one count), so its decision is FINAL whenever no boundary lies
+// within (eps*T + p) of u*T -- whatever the earlier draws of the window turn out
+// to be.  Each pass accepts the draws in front of the first one that fails this
+// test (one LDS float atomic per accepted draw; the waves exchange the position
+// through LDS) and the window moves on to that draw, which then has p = 0 and
+// margin eps*T only.  A draw that fails at p = 0 is within the fp32 error bound
+// of a boundary (or its slot is flagged): wave 0 sends it through the fp64 scan
+// and, if needed, the literal evaluation.  eps bounds the fp32 error of the
+// chains and sums, < (2*S + 9) * 2^-24 relative to T.
 //
-// Strains are handled in blocks of 16 (NB blocks, compile time; padding has
-// weight 0): block-local chains, block offsets folded into the comparison value.
-// Weight rows are row-major [Q][stride], stride = 4 * odd, so that the 16-byte
-// reads of 64 lanes (consecutive rows) spread over all LDS banks.
+// Weight rows are row-major [Q][stride] fp32, stride = 4 * odd.
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
+typedef int i4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float fma_rn(float a, float b, float c) {       // three-address FMA (no v_fmac + copy)
     float d;
@@ -707,18 +709,26 @@ __device__ __forceinline__ float min3_abs(float m, float x, float y) {
     asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(d) : "v"(m), "v"(x), "v"(y));
     return d;
 }
+template <int QP> __device__ __forceinline__ float quad_f32(float v) {     // quad_perm DPP
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), QP, 0xF, 0xF, true));
+}
+template <int QP> __device__ __forceinline__ int quad_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, QP, 0xF, 0xF, true);
+}
+// LDS-only workgroup barrier: does not wait for outstanding global loads / stores
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int UWIN = 1024;     // uniforms staged in LDS (fp32), refilled in halves
 
-template <int NB, bool ROWS_LDS>
-__device__ __forceinline__ void urn_chain_w(const JobDev& job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
+template <int NQ, bool ROWS_LDS>
+__device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
                                             const int* s_slot, volatile double* s_a, volatile double* s_p, float* s_kf,
-                                            const float* s_a0f, float* s_uwin, const float* rows_lds, int stride, int lane) {
-    constexpr int SP = 16 * NB, NG = 4 * NB;
+                                            const float* s_a0f, int* s_x, float* s_uwin, const float* rows_lds, int stride, int tid) {
+    constexpr int SPL = 4 * NQ, SP = 16 * NQ;               // strains per lane, capacity
     constexpr int NPLC = SP > 64 ? 2 : 1;                  // strains per lane in the checked tier
     constexpr float EPSW = (float)(SP + 12) * 1.5e-7f;
     constexpr float BIG = 1.0e30f;
-    constexpr bool A0REG = NB <= 4;
+    const int lane = tid & 63, wv = tid >> 6, k = lane & 3, pos = wv * 16 + (lane >> 2);
     const int S = P->S, Q = P->Q, n = P->n_sweeps, e0 = P->e0;
     const int Sm1 = S - 1;
     const int total = n * Q;
@@ -732,114 +742,113 @@ __device__ __forceinline__ void urn_chain_w(const JobDev& job, const LevelParams
     };
     auto ld1 = [&](int idx) __attribute__((always_inline)) -> float { return ROWS_LDS ? rows_lds[idx] : rows_g[idx]; };
 
-    double a0m[NPLC];
+    const int cbase = k * SPL;                              // first strain of this lane's quarter
+    const float m0 = k > 0 ? 1.0f : 0.0f, m1 = k > 1 ? 1.0f : 0.0f, m2 = k > 2 ? 1.0f : 0.0f;
+    const float posf = (float)pos + 1.0e-37f;
+    double a0m[NPLC];                                       // wave 0, checked tier: strains across the lanes
 #pragma unroll
     for (int i = 0; i < NPLC; i++) { const int s = lane * NPLC + i; a0m[i] = (s < S) ? P->a0[s] : 0.0; }
-    f4v a0u[A0REG ? NG : 1];
-    if (A0REG) {
+    f4v a0q[NQ];
 #pragma unroll
-        for (int g = 0; g < NG; g++) a0u[A0REG ? g : 0] = *(const f4v*)(s_a0f + 4 * g);
-    }
+    for (int g = 0; g < NQ; g++) a0q[g] = *(const f4v*)(s_a0f + cbase + 4 * g);
     unsigned long long n_exact = 0, n_slow = 0, n_pass = 0;
     const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
 
-    // uniforms: draws [ulo, ulo + UWIN) live in s_uwin[p & (UWIN-1)]
+    // uniforms: draws [ulo, ulo + UWIN) live in s_uwin[p & (UWIN-1)]; wave 0 refills
     int ulo = 0;
     bool upf = false;
     f4v ux0 = 0.0f, ux1 = 0.0f;
+    if (wv == 0) {
 #pragma unroll
-    for (int k = 0; k < UWIN / 256; k++) *(f4v*)(s_uwin + 256 * k + 4 * lane) = *(const SC_GLOBAL f4v*)(Uf + 256 * k + 4 * lane);
+        for (int j = 0; j < UWIN / 256; j++) *(f4v*)(s_uwin + 256 * j + 4 * lane) = *(const SC_GLOBAL f4v*)(Uf + 256 * j + 4 * lane);
+    }
+    __syncthreads();
 
-    constexpr int NSB = 2 * NB;                            // sub-blocks of eight strains: independent FMA chains
     int t = 0;
-    int ro = (lane % Q) * stride;                          // row offset (floats) of this lane's draw
+    int ro = (pos % Q) * stride;                            // row offset (floats) of this lane's draw
     const int wrap = Q * stride;
-    int upos = lane;                                       // (t + lane) & (UWIN - 1)
-    const float lanef = (float)lane + 1.0e-37f;
-    f4v L[NG];
+    int upos = pos;                                        // (t + pos) & (UWIN - 1)
+    f4v L[NQ];
     float uf = 0.0f, llast = 0.0f;
     auto issue_loads = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int g = 0; g < NG; g++) L[g] = ld4(ro + 4 * g);
+        for (int g = 0; g < NQ; g++) L[g] = ld4(ro + cbase + 4 * g);
         llast = ld1(ro + Sm1);
         uf = s_uwin[upos];
     };
-    __builtin_amdgcn_wave_barrier();
     if (total > 0) issue_loads();
 #pragma unroll 1
     while (t < total) {
         asm volatile("" ::: "memory");                      // s_kf below must be re-read
         n_pass++;
-        // pass 1: sub-block-local cumulative weights with the counts in front of draw t
-        f4v av[NG];
+        // this lane's quarter: cumulative weights with the counts in front of draw t
+        float loc[SPL];
+        float run = 0.0f;
 #pragma unroll
-        for (int g = 0; g < NG; g++)
-            av[g] = (A0REG ? a0u[A0REG ? g : 0] : *(const f4v*)(s_a0f + 4 * g)) + *(const f4v*)(s_kf + 4 * g);
+        for (int g = 0; g < NQ; g++) {
+            const f4v av = a0q[g] + *(const f4v*)(s_kf + cbase + 4 * g);
+            loc[4 * g + 0] = run = (g == 0) ? av.x * L[g].x : fma_rn(av.x, L[g].x, run);
+            loc[4 * g + 1] = run = fma_rn(av.y, L[g].y, run);
+            loc[4 * g + 2] = run = fma_rn(av.z, L[g].z, run);
+            loc[4 * g + 3] = run = fma_rn(av.w, L[g].w, run);
+        }
         const float alast = s_a0f[Sm1] + s_kf[Sm1];
-        float loc[SP], run[NSB];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-#pragma unroll
-            for (int sb = 0; sb < NSB; sb++) {
-                const int sidx = 8 * sb + j;
-                const float aa = av[sidx >> 2][sidx & 3], ll = L[sidx >> 2][sidx & 3];
-                run[sb] = (j == 0) ? aa * ll : fma_rn(aa, ll, run[sb]);
-                loc[sidx] = run[sb];
-            }
-        }
-        float off[NSB + 1];
-        off[0] = 0.0f;
-#pragma unroll
-        for (int sb = 0; sb < NSB; sb++) off[sb + 1] = off[sb] + run[sb];
-        const float T = off[NSB];
-        // pass 2: position of u*T among the boundaries and the distance to the nearest one
+        // quad: offset of this quarter and the total weight (bitwise the same in the four lanes)
+        const float off = fmaf(quad_f32<0xAA>(run), m2, fmaf(quad_f32<0x55>(run), m1, quad_f32<0x00>(run) * m0));
+        const float h = run + quad_f32<0xB1>(run);
+        const float T = h + quad_f32<0x4E>(h);
+        // position of u*T among the boundaries and the distance to the nearest one
         const float tgt = uf * T;
-        f2v tb2[NSB];
+        const float tb = tgt - off;
+        const f2v tb2 = {tb, tb};
+        unsigned w = 0;
+        float dm = BIG;
 #pragma unroll
-        for (int sb = 0; sb < NSB; sb++) { const float tb = tgt - off[sb]; tb2[sb] = f2v{tb, tb}; }
-        unsigned w[NSB];
-        float dm0 = BIG, dm1 = BIG;
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-#pragma unroll
-            for (int sb = 0; sb < NSB; sb++) {
-                const f2v lc = {loc[8 * sb + j], loc[8 * sb + j + 1]};
-                const f2v d = pk_sub(lc, tb2[sb]);
-                w[sb] = __builtin_amdgcn_alignbit(j == 0 ? 0u : w[sb], __float_as_uint(d.x), 31);   // (w << 1) | sign(d)
-                w[sb] = __builtin_amdgcn_alignbit(w[sb], __float_as_uint(d.y), 31);
-                if (sb & 1) dm1 = min3_abs(dm1, d.x, d.y); else dm0 = min3_abs(dm0, d.x, d.y);
-            }
+        for (int j = 0; j < SPL; j += 2) {
+            const f2v lc = {loc[j], loc[j + 1]};
+            const f2v d = pk_sub(lc, tb2);
+            w = __builtin_amdgcn_alignbit(w, __float_as_uint(d.x), 31);   // (w << 1) | sign(d)
+            w = __builtin_amdgcn_alignbit(w, __float_as_uint(d.y), 31);
+            dm = min3_abs(dm, d.x, d.y);
         }
-        int c = 0;
-#pragma unroll
-        for (int sb = 0; sb < NSB; sb++) c += __popc(w[sb]);
+        int c = __popc(w);
+        c += quad_i32<0xB1>(c);
+        c += quad_i32<0x4E>(c);
+        dm = fminf(dm, quad_f32<0xB1>(dm));
+        dm = fminf(dm, quad_f32<0x4E>(dm));
         // Strains >= S-1 and the padding all sit at cum = T >= u*T.  They never count (a padding entry
         // can round to a tiny negative difference: the count is clamped), and their distance T - u*T
         // must not enter the margin test: alt = -(cum_{S-2} - u*T) is <= 0 while a real boundary lies
         // at or above u*T and is the distance to the nearest real boundary when none does.
         c = min(c, Sm1);
         const float alt = tgt - (T - alast * llast);
-        const float dmin = fmaxf(fminf(dm0, dm1), alt);
-        const float lim = fmaf(EPSW, T, lanef);             // NaN (flagged slot) and T == 0 fail the test
+        const float dmin = fmaxf(dm, alt);
+        const float lim = fmaf(EPSW, T, posf);              // NaN (flagged slot) and T == 0 fail the test
         const unsigned long long F = ~__ballot(dmin >= lim);
+        const int fpos = F ? 16 * wv + ((int)__builtin_ctzll(F) >> 2) : 64;
+        if (lane == 0) s_x[wv] = fpos;
+        lds_barrier();
+        const i4v xf = *(const i4v*)s_x;
         const int rem = total - t;
-        int adv = F ? (int)__builtin_ctzll(F) : 64;
+        int adv = min(min(xf.x, xf.y), min(xf.z, xf.w));
         adv = adv < rem ? adv : rem;
         if (adv == 0) {
-            // draw t itself: fp64 scan with the exact counts, then the literal tier
-            const double u = Ustream[t];
-            double ad[NPLC];
+            // draw t itself: fp64 scan with the exact counts, then the literal tier (wave 0)
+            if (wv == 0) {
+                const double u = Ustream[t];
+                double ad[NPLC];
 #pragma unroll
-            for (int i = 0; i < NPLC; i++) { const int s = lane * NPLC + i; ad[i] = a0m[i] + (double)((s < S) ? s_kf[s] : 0.0f); }
-            const int qi = __builtin_amdgcn_readfirstlane(ro) / stride;
-            int cc = slow_draw<NPLC>(sa, s_slot, s_a, s_p, ad[0], NPLC > 1 ? ad[NPLC - 1] : 0.0, S, qi, e0, u, lane);
-            n_slow++;
-            n_exact += (cc >> 8) & 1;
-            c = cc & 0xFF;
+                for (int i = 0; i < NPLC; i++) { const int s = lane * NPLC + i; ad[i] = a0m[i] + (double)((s < S) ? s_kf[s] : 0.0f); }
+                const int qi = __builtin_amdgcn_readfirstlane(ro) / stride;
+                const int cc = slow_draw<NPLC>(sa, s_slot, s_a, s_p, ad[0], NPLC > 1 ? ad[NPLC - 1] : 0.0, S, qi, e0, u, lane);
+                n_slow++;
+                n_exact += (cc >> 8) & 1;
+                c = cc & 0xFF;
+            }
             adv = 1;
         }
-        const bool acc = lane < adv;
-        if (acc) rec[t + lane] = (uint8_t)c;
+        const bool acc = (pos < adv) && (k == 0);
+        if (acc) rec[t + pos] = (uint8_t)c;
         t += adv;
         if (t >= total) {
             if (acc) __hip_atomic_fetch_add(&s_kf[c], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -854,31 +863,35 @@ __device__ __forceinline__ void urn_chain_w(const JobDev& job, const LevelParams
         }
         upos = (upos + adv) & (UWIN - 1);
         // uniforms: prefetch the next half window, swap it in when the window has moved past the old one
-        if (!upf && t >= ulo + UWIN / 4) {
-            ux0 = *(const SC_GLOBAL f4v*)(Uf + ulo + UWIN + 4 * lane);
-            ux1 = *(const SC_GLOBAL f4v*)(Uf + ulo + UWIN + 256 + 4 * lane);
-            upf = true;
+        if (wv == 0) {
+            if (!upf && t >= ulo + UWIN / 4) {
+                ux0 = *(const SC_GLOBAL f4v*)(Uf + ulo + UWIN + 4 * lane);
+                ux1 = *(const SC_GLOBAL f4v*)(Uf + ulo + UWIN + 256 + 4 * lane);
+                upf = true;
+            }
+            if (t >= ulo + UWIN / 2) {
+                *(f4v*)(s_uwin + ((ulo & (UWIN - 1)) + 4 * lane)) = ux0;
+                *(f4v*)(s_uwin + ((ulo & (UWIN - 1)) + 256 + 4 * lane)) = ux1;
+                ulo += UWIN / 2;
+                upf = false;
+            }
         }
-        if (t >= ulo + UWIN / 2) {
-            *(f4v*)(s_uwin + ((ulo & (UWIN - 1)) + 4 * lane)) = ux0;
-            *(f4v*)(s_uwin + ((ulo & (UWIN - 1)) + 256 + 4 * lane)) = ux1;
-            ulo += UWIN / 2;
-            upf = false;
-        }
-        issue_loads();                                       // rows of the new window first, then the commit, then the counts
+        issue_loads();                                       // rows of the new window first, then the commit
         if (acc) __hip_atomic_fetch_add(&s_kf[c], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_barrier();                                       // every wave's commits are in s_kf
     }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if (wv == 0) {
 #pragma unroll
-    for (int i = 0; i < NPLC; i++) {
-        const int s = lane * NPLC + i;
-        if (s < S) R->abund[s] = a0m[i] + (double)s_kf[s];
-    }
-    if (lane == 0) {
-        R->n_draws = (unsigned long long)total; R->n_exact = n_exact; R->n_slow = n_slow; R->n_redo = n_pass;
-        R->n_careful = n_slow;
-        R->chain_cycles = clock64() - clk0; R->chain_wall = wall_clock64() - wall0; R->redo_cycles = 0;
+        for (int i = 0; i < NPLC; i++) {
+            const int s = lane * NPLC + i;
+            if (s < S) R->abund[s] = a0m[i] + (double)s_kf[s];
+        }
+        if (lane == 0) {
+            R->n_draws = (unsigned long long)total; R->n_exact = n_exact; R->n_slow = n_slow; R->n_redo = n_pass;
+            R->n_careful = n_slow;
+            R->chain_cycles = clock64() - clk0; R->chain_wall = wall_clock64() - wall0; R->redo_cycles = 0;
+        }
     }
 }
 
@@ -1216,6 +1229,7 @@ __global__ __launch_bounds__(256) void k_chain_w(JobDev job, const LevelParams* 
     int* s_slot = reinterpret_cast<int*>(s_cnt + MAXS * KMAX);   // [MAXS]
     float* s_kf = reinterpret_cast<float*>(s_slot + MAXS);       // [MAXS] draws per strain so far
     float* s_a0f = s_kf + MAXS;                                  // [MAXS] fp32 copy of the starting weights
+    int* s_x = reinterpret_cast<int*>(s_a0f + MAXS);             // [4] first failing position per wave
     float* s_uwin = reinterpret_cast<float*>(s_raw + LDS_SMALL); // [UWIN]
     float* s_rows = s_uwin + UWIN;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1249,8 +1263,8 @@ __global__ __launch_bounds__(256) void k_chain_w(JobDev job, const LevelParams* 
         // a single candidate takes every draw (discrete_distribution with one weight)
         for (int t = tid; t < total; t += nt) job.rec[t] = 0;
         if (tid == 0) { R->abund[0] = P->a0[0] + (double)total; R->n_draws = (unsigned long long)total; }
-    } else if (tid < 64) {
-        urn_chain_w<NB, ROWS_LDS>(job, P, R, s_slot, s_a, s_p, s_kf, s_a0f, s_uwin, s_rows, stride, tid);
+    } else {
+        urn_chain_q<NB, ROWS_LDS>(job, P, R, s_slot, s_a, s_p, s_kf, s_a0f, s_x, s_uwin, s_rows, stride, tid);
     }
     __syncthreads();
     // draws per (strain, read symbol): the substitution counts of :198-206
