@@ -161,7 +161,7 @@ struct Worker {
     LevelResult* Rh = nullptr;        // host-mapped, written by the kernel
     LevelResult* Rd = nullptr;
     DevBuf b_ent_rid, b_ent_cn, b_ent_lab_off, b_ent_lab_len, b_ent_first, b_ent_qoff, b_labels, b_mate_ptr, b_mate_idx,
-        b_ll, b_has, b_isnew, b_tabA, b_tabL, b_tabLf, b_rec, b_qflag, b_qcode, b_qent, b_quid, b_out_ptr, b_out_node, b_pool_ptr, b_pool_rid,
+        b_ll, b_has, b_isnew, b_tabA, b_tabL, b_tabLf, b_qflag, b_qcode, b_qent, b_quid, b_out_ptr, b_out_node, b_pool_ptr, b_pool_rid,
         b_pool_cn, b_isend, b_esrc, b_support;
     DevBuf m_seqs, m_off, m_cols0, m_cols1, m_counts, m_moves, m_trace, m_out;
     DevBuf t_ref, t_pos, t_seqoff, t_seq, t_cigoff, t_cigop, t_ciglen, t_lut, t_tabs, t_pool, t_pool2;
@@ -367,7 +367,6 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     jd.tabA = (double*)b_tabA.ensure(sizeof(double) * (size_t)qcap * MAXS);
     jd.qmax = (double*)b_tabL.ensure(sizeof(double) * (size_t)qcap);
     jd.tabLf = (float*)b_tabLf.ensure(sizeof(float) * (size_t)(std::min<long>(qcap, MAX_DRAWS) + 4) * 136);
-    jd.rec = (uint8_t*)b_rec.ensure((size_t)MAX_DRAWS + 64);
     jd.qflag = (uint8_t*)b_qflag.ensure((size_t)qcap + 8);
     jd.qcode = (uint8_t*)b_qcode.ensure((size_t)qcap + 8);
     jd.qent = (int*)b_qent.ensure(sizeof(int) * (size_t)qcap);
@@ -497,10 +496,11 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         if (timed) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
-            if (level_log) fprintf(level_log, "S %d Q %d n %d ms %.4f redo %llu careful %llu slow %llu cyc %llu redocyc %llu ph %llu %llu %llu\n", S, Q, n_sweeps, ms,
+            if (level_log) fprintf(level_log, "S %d Q %d n %d ms %.4f redo %llu careful %llu slow %llu cyc %llu redocyc %llu ph %llu %llu %llu %llu %llu\n", S, Q, n_sweeps, ms,
                                    (unsigned long long)Rh->n_redo, (unsigned long long)Rh->n_careful, (unsigned long long)Rh->n_slow,
                                    (unsigned long long)Rh->chain_cycles, (unsigned long long)Rh->redo_cycles,
-                                   (unsigned long long)Rh->phase[0], (unsigned long long)Rh->phase[1], (unsigned long long)Rh->phase[2]);
+                                   (unsigned long long)Rh->phase[0], (unsigned long long)Rh->phase[1], (unsigned long long)Rh->phase[2],
+                                   (unsigned long long)Rh->phase[3], (unsigned long long)Rh->phase[4]);
             sampler_ms += ms;
         }
     };

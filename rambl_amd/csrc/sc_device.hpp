@@ -44,7 +44,6 @@ struct JobDev {
     uint8_t* qcode;              // [qcap] read-label symbol code of a draw slot (0xFF: not a single symbol)
     int* qent;                   // [qcap] entry index of a draw slot
     int* quid;                   // [qcap] mate read id of a draw slot (-1 none)
-    uint8_t* rec;                // [MAX_DRAWS + 64] strain chosen by each draw of the current sampler launch
     long qcap;
 };
 
@@ -79,7 +78,7 @@ struct LevelResult {
     unsigned long long redo_cycles;  // shader cycles spent replaying flagged blocks
     unsigned long long chain_cycles, chain_wall;   // shader cycles / 100 MHz ticks spent in the urn chain
     unsigned long long n_exact;  // draws resolved by the literal fp64 path
-    unsigned long long phase[4]; // diagnostics (SC_PHASE_TIMING builds): shader cycles per phase of the wide chain
+    unsigned long long phase[6]; // diagnostics (SC_PHASE_TIMING builds): shader cycles per phase of the wide chain
     int error;
 };
 

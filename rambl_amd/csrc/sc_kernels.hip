@@ -26,12 +26,8 @@ namespace sc {
 constexpr int LDS_TOTAL = 160 * 1024 - 256;   // dynamic part; the rest covers small static __shared__ variables
 constexpr int LDS_SMALL = 9 * 1024;            // per-strain scalars
 constexpr int LDS_BIG = LDS_TOTAL - LDS_SMALL;
-constexpr int LDS_REC = MAX_DRAWS + 64;
-constexpr int LDS_ROWS_FLOATS = (LDS_BIG - LDS_REC) / 4;    // two-strains-per-lane path (S > 64)
-constexpr int LDS_UBUF = 4096;                            // 1024 staged uniforms (S <= 64 path)
 static_assert(LDS_SMALL >= (int)(sizeof(double) * 3 * MAXS + sizeof(unsigned) * MAXS * KMAX + sizeof(int) * 3 * MAXS + 64), "LDS_SMALL");
 static_assert(LDS_BIG >= (int)(sizeof(double) * MAXS * KK), "LDS_BIG");
-static_assert(LDS_REC % 4 == 0, "LDS_REC");
 
 // --------------------------------------------------------------------------
 // wave64 helpers
@@ -143,7 +139,6 @@ __device__ int exact_draw(const SlowArgs job, const int* s_slot, const volatile 
 }
 
 constexpr double DRAW_EPS64 = 1e-10;  // margin (relative to the total weight) of the fp64 scan tier
-constexpr float DRAW_EPS32 = 1e-5f;   // margin of the fp32 scan tier (fp32 scan error <= ~6e-7 of the total)
 
 template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
 __device__ __forceinline__ float dpp_f32(float v) {
@@ -207,467 +202,6 @@ __device__ __noinline__ int slow_draw(const SlowArgs job, const int* s_slot, vol
     return c;
 }
 
-// The urn chain: NonparametricClustering.cpp:161-210 (and :796-829).  One
-// wavefront; NPL strains per lane (strain index = lane*NPL + i).
-// Tier 1 per draw: fp32 weights a_s * L[q][s] (L = exp(loglik - max), staged in
-// LDS when it fits, ROWS_LDS), DPP prefix scan, two ballots around u*T.  The
-// chosen strain is recorded per draw (one byte) and histogrammed afterwards.
-template <int NPL, bool ROWS_LDS>
-__device__ void urn_chain(const JobDev& job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
-                          const int* s_slot, volatile double* s_a, volatile double* s_p, unsigned char* rec,
-                          const float* rows_lds, int lane) {
-    const int S = P->S, Q = P->Q, n = P->n_sweeps, e0 = P->e0;
-    constexpr int SPAD = 64 * NPL;
-    const SlowArgs sa{job.tabA, job.qmax, job.qcap, job.qflag, job.qent, job.quid, job.ent_rid, job.ll, job.ll_stride, job.has};
-    const double* Ustream = job.U;
-    const float* rows = ROWS_LDS ? rows_lds : job.tabLf;
-    const int stride = ROWS_LDS ? S : SPAD;
-    double a[NPL];
-    float af[NPL];
-    bool act[NPL];
-#pragma unroll
-    for (int i = 0; i < NPL; i++) {
-        const int s = lane * NPL + i;
-        act[i] = s < S;
-        a[i] = act[i] ? P->a0[s] : 0.0;
-        af[i] = (float)a[i];
-    }
-    unsigned long long n_exact = 0, n_slow = 0;
-    const int total = n * Q;
-    constexpr int PF = ROWS_LDS ? 2 : 8;                 // draws of row prefetch
-    float rowbuf[PF][NPL];
-    int qpf = 0;
-#pragma unroll
-    for (int d = 0; d < PF; d++) {
-#pragma unroll
-        for (int i = 0; i < NPL; i++) rowbuf[d][i] = act[i] ? rows[qpf * stride + lane * NPL + i] : 0.0f;
-        qpf = (qpf + 1 == Q) ? 0 : qpf + 1;
-    }
-    int q = 0;
-    double ublk = 0;
-    float ublkf = 0;
-    unsigned crec = 0;
-    for (int t = 0; t < total; t++) {
-        const int tl = t & 63;
-        if (tl == 0) {
-            ublk = (t + lane < MAX_DRAWS) ? Ustream[t + lane] : 0.0;
-            ublkf = (float)ublk;
-        }
-        const float uf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublkf), tl));
-        float L[NPL];
-#pragma unroll
-        for (int i = 0; i < NPL; i++) L[i] = rowbuf[0][i];
-#pragma unroll
-        for (int d = 0; d + 1 < PF; d++)
-#pragma unroll
-            for (int i = 0; i < NPL; i++) rowbuf[d][i] = rowbuf[d + 1][i];
-#pragma unroll
-        for (int i = 0; i < NPL; i++) rowbuf[PF - 1][i] = act[i] ? rows[qpf * stride + lane * NPL + i] : 0.0f;
-        qpf = (qpf + 1 == Q) ? 0 : qpf + 1;
-
-        float w[NPL], pair = 0.0f;
-#pragma unroll
-        for (int i = 0; i < NPL; i++) { w[i] = af[i] * L[i]; pair += w[i]; }
-        const float incl = wave_scan_incl_f32(pair);
-        const float T = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
-        const float tgt = uf * T, mg = DRAW_EPS32 * T;
-        const float lo = tgt - mg, hi = tgt + mg;
-        int c;
-        bool fast = (T > 0.0f) && (T < 1.0e30f);         // a flagged slot has a NaN row: T is NaN
-        if (NPL == 1) {
-            const unsigned long long mlo = __ballot(incl >= lo), mhi = __ballot(incl >= hi);
-            fast = fast && (mlo == mhi) && (mlo != 0ull);
-            c = (int)__builtin_ctzll(mlo | (1ull << 63));
-        } else {
-            const float E = dpp_f32<0x138, 0xF, 0xF, true>(incl);   // wave_shr:1
-            const float c0 = E + w[0], c1 = E + pair;
-            const unsigned long long m0lo = __ballot(c0 >= lo), m0hi = __ballot(c0 >= hi);
-            const unsigned long long m1lo = __ballot(c1 >= lo), m1hi = __ballot(c1 >= hi);
-            fast = fast && (m0lo == m0hi) && (m1lo == m1hi) && (m1lo != 0ull);
-            const int l1 = (int)__builtin_ctzll(m1lo | (1ull << 63));
-            c = 2 * l1 + (((m0lo >> l1) & 1ull) ? 0 : 1);
-        }
-        if (!fast) {
-            const double u = readlane_f64(ublk, tl);
-            c = slow_draw<NPL>(sa, s_slot, s_a, s_p, a[0], NPL > 1 ? a[NPL - 1] : 0.0, S, q, e0, u, lane);
-            n_slow++;
-            n_exact += (c >> 8) & 1;
-            c &= 0xFF;
-        }
-#pragma unroll
-        for (int i = 0; i < NPL; i++) {
-            a[i] += (lane * NPL + i == c) ? 1.0 : 0.0;
-            af[i] = (float)a[i];
-        }
-        crec = (lane == tl) ? (unsigned)c : crec;
-        if (tl == 63) rec[t - 63 + lane] = (unsigned char)crec;
-        q = (q + 1 == Q) ? 0 : q + 1;
-    }
-    if (total & 63) { const int base = total & ~63; if (base + lane < total) rec[base + lane] = (unsigned char)crec; }
-#pragma unroll
-    for (int i = 0; i < NPL; i++) { int s = lane * NPL + i; if (s < S) R->abund[s] = a[i]; }
-    if (lane == 0) { R->n_draws = (unsigned long long)total; R->n_exact = n_exact; R->n_slow = n_slow; }
-}
-
-// --------------------------------------------------------------------------
-// Grouped urn chain for S <= 64: four draws per iteration.
-//
-// The wave is split into its four DPP rows; row r works on draw t+r of a batch of
-// four, with the 16 lanes of a row holding NPL = 1, 2 or 4 consecutive strains
-// each (strain = col*NPL + i).  Every row carries a replica of the per-strain
-// counts k.  All four draws of a batch are decided from the counts at the START
-// of the batch; draw r is accepted only if no boundary lies within
-// (1e-5*T + r) of u*T -- r bounds the shift the <= r earlier draws of the batch
-// can cause, because every weight factor L is <= 1.  The chain per batch is:
-// in-lane prefix -> 4-step row scan (row_shr) -> T by row_newbcast:15 -> compares
-// -> sum of the selections over the rows (v_permlane16_swap, v_permlane32_swap)
-// -> k += sum.  Eight batches form a block; one ballot per block tests the sticky
-// per-lane flags.  A flagged block restores k and replays its 32 draws one at a
-// time (row 0 only) through the checked tiers.
-typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float rows_sum4(float x) {
-    uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    const float y = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    uint2v r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
-    return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
-}
-__device__ __forceinline__ float row_scan16(float v) {
-    v += dpp_f32<0x111, 0xF, 0xF, true>(v);
-    v += dpp_f32<0x112, 0xF, 0xF, true>(v);
-    v += dpp_f32<0x114, 0xF, 0xF, true>(v);
-    v += dpp_f32<0x118, 0xF, 0xF, true>(v);
-    return v;
-}
-
-// Tier 2 (sequential fp64 with a 1e-10 margin) and tier 3 (literal) for one draw,
-// run by lane 0; s_a holds the current urn weights a_s.
-__device__ __noinline__ int slow_draw_seq(const SlowArgs job, const int* s_slot, const volatile double* s_a,
-                                          volatile double* s_p, int S, int q, int e0, double u, int* tier3) {
-    *tier3 = 0;
-    if (!job.qflag[q]) {
-        const double m = job.qmax[q];
-        double T = 0;
-        for (int s = 0; s < S; s++) { T += s_a[s] * exp(job.tabA[(long)s * job.qcap + q] - m); s_p[s] = T; }
-        if (T > 0.0 && T < 1.0e300) {
-            const double tgt = u * T, mg = DRAW_EPS64 * T;
-            int c = -1;
-            bool ok = true;
-            for (int s = 0; s < S; s++) {
-                const double cum = s_p[s];
-                if (fabs(cum - tgt) < mg) ok = false;
-                if (c < 0 && cum >= tgt) c = s;
-            }
-            if (!(tgt >= mg)) ok = false;
-            if (ok && c >= 0) return c;
-        }
-    }
-    *tier3 = 1;
-    return exact_draw(job, s_slot, s_a, s_p, S, job.ent_rid[e0 + job.qent[q]], job.quid[q], u);
-}
-
-template <int NPL, bool ROWS_LDS>
-__device__ __forceinline__ void urn_chain_g4(const JobDev& job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
-                             const int* s_slot, volatile double* s_a, volatile double* s_p, unsigned* s_cnt,
-                             const float* rows_lds, const unsigned char* qcode_lds, float* ubuf, int any_flag, int lane) {
-    // Table layout expected from k_chain: rows [Q + 3][stride] (slots 0..2 repeated after the last,
-    // then zeros), qcode [Q + 3] (same), so that a batch starting at slot q < Q never wraps.
-    const int S = P->S, Q = P->Q, n = P->n_sweeps, e0 = P->e0;
-    const int row = lane >> 4, col = lane & 15;
-    constexpr int BB = 4;                                  // batches per block (16 draws)
-    constexpr int UB = 1024;                               // uniforms staged in LDS at a time
-    constexpr float BIG = 1.0e30f;
-    const SlowArgs sa{job.tabA, job.qmax, job.qcap, job.qflag, job.qent, job.quid, job.ent_rid, job.ll, job.ll_stride, job.has};
-    const SC_GLOBAL double* Ustream = (const SC_GLOBAL double*)job.U;
-    const SC_GLOBAL float* rows_g = (const SC_GLOBAL float*)job.tabLf;
-    const int stride = ROWS_LDS ? S : 64;
-    auto ld_row = [&](int idx) __attribute__((always_inline)) -> float { return ROWS_LDS ? rows_lds[idx] : rows_g[idx]; };
-    bool act[NPL];
-    double a0[NPL];
-    float a0f[NPL], kf[NPL];
-    unsigned cnt[NPL][KMAX];
-#pragma unroll
-    for (int i = 0; i < NPL; i++) {
-        const int s = col * NPL + i;
-        act[i] = s < S;
-        a0[i] = act[i] ? P->a0[s] : 0.0;
-        a0f[i] = (float)a0[i];
-        kf[i] = 0.0f;
-#pragma unroll
-        for (int b = 0; b < KMAX; b++) cnt[i][b] = 0;
-    }
-    unsigned long long n_exact = 0, n_slow = 0, n_redo = 0, n_careful = 0, redo_cycles = 0;
-    const int total = n * Q;
-    const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
-    const float mg_add = (float)row + 1.0e-37f;            // draw r of a batch tolerates r earlier increments
-    const int lane_row_off = row * stride + col * NPL;     // + q*stride = this lane's weights of draw slot q+row
-
-    // ---- level C: one draw at a time on row 0 through the checked tiers; count <= 64
-    auto careful_draws = [&](int t_begin, int count, int q_begin) __attribute__((always_inline)) {
-        int ql = q_begin + lane;
-        ql = ql >= Q ? ql % Q : ql;
-        const double ublk = (lane < count) ? Ustream[t_begin + lane] : 0.0;
-        const int cblk = qcode_lds[ql];
-        int qq = q_begin;
-        for (int d = 0; d < count; d++) {
-            const double u = readlane_f64(ublk, d);
-            const float uf = (float)u;
-            const int code = __builtin_amdgcn_readlane(cblk, d) >> 2;      // staged as 4*min(symbol, KMAX-1)
-            float pre[NPL];
-            float tot = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NPL; i++) {
-                const float L = (act[i] && row == 0) ? ld_row(qq * stride + col * NPL + i) : 0.0f;
-                tot += (a0f[i] + kf[i]) * L;
-                pre[i] = tot;
-            }
-            const float incl = row_scan16(tot);
-            const float base = dpp_f32<0x111, 0xF, 0xF, true>(incl);
-            const float T = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 15));
-            const float tgt = uf * T, mg = DRAW_EPS32 * T + 1.0e-37f;
-            bool near = !(fabsf(base - tgt) >= mg);
-            int csel = -1;
-            float prev = (col == 0) ? -1.0f : base;
-#pragma unroll
-            for (int i = 0; i < NPL; i++) {
-                const float cum = (i == NPL - 1) ? incl : base + pre[i];
-                near = near || !(fabsf(cum - tgt) >= mg);
-                if (cum >= tgt && !(prev >= tgt)) csel = col * NPL + i;
-                prev = cum;
-            }
-            const unsigned long long rowmask = 0xFFFFull;
-            const bool unsafe = !(T > 0.0f) || !(T < 1.0e30f) || ((__ballot(near) & rowmask) != 0ull);
-            const unsigned long long hit = __ballot(csel >= 0) & rowmask;
-            int c;
-            if (!unsafe && hit != 0ull) {
-                c = __builtin_amdgcn_readlane(csel, (int)__builtin_ctzll(hit));
-            } else {
-                if (row == 0) {
-#pragma unroll
-                    for (int i = 0; i < NPL; i++) { const int s = col * NPL + i; if (s < S) s_a[s] = a0[i] + (double)kf[i]; }
-                }
-                __builtin_amdgcn_wave_barrier();
-                int cc = 0, t3 = 0;
-                if (lane == 0) cc = slow_draw_seq(sa, s_slot, s_a, s_p, S, qq, e0, u, &t3);
-                c = __builtin_amdgcn_readfirstlane(cc);
-                n_exact += (unsigned long long)__builtin_amdgcn_readfirstlane(t3);
-                __builtin_amdgcn_wave_barrier();
-                n_slow++;
-            }
-#pragma unroll
-            for (int i = 0; i < NPL; i++) {
-                const bool mine = (col * NPL + i == c);
-                kf[i] += mine ? 1.0f : 0.0f;                 // every row keeps its replica in step
-                if (row == 0 && mine) {
-#pragma unroll
-                    for (int b = 0; b < KMAX; b++) cnt[i][b] += (code == b) ? 1u : 0u;
-                }
-            }
-            qq = (qq + 1 == Q) ? 0 : qq + 1;
-        }
-        n_careful += count;
-    };
-
-    // ---- level B: replay of a flagged block, one draw per iteration, same branch-free body as a
-    // batch (every row computes the SAME draw, so the replicas stay in step without an exchange);
-    // one test at the end; still flagged -> level C.  count <= 64.
-    auto replay_draws = [&](int t_begin, int count, int q_begin) __attribute__((always_inline)) {
-        float kf1[NPL];
-        unsigned pk[NPL], pk2[NPL];                          // 4-bit fields: even / odd draws (<= 8 each)
-#pragma unroll
-        for (int i = 0; i < NPL; i++) { kf1[i] = kf[i]; pk[i] = 0; pk2[i] = 0; }
-        int ql = q_begin + lane;
-        ql = ql >= Q ? ql % Q : ql;
-        const float ublkf = (lane < count) ? (float)Ustream[t_begin + lane] : 0.0f;
-        const int cblk = qcode_lds[ql];
-        float slack = 1.0e30f;
-        int qq = q_begin;
-        const int lo = col * NPL;
-        for (int d = 0; d < count; d++) {
-            const float uf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublkf), d));
-            const unsigned sh = (unsigned)__builtin_amdgcn_readlane(cblk, d);
-            float pre[NPL], tot = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NPL; i++) { tot += (a0f[i] + kf[i]) * ld_row(qq * stride + lo + i); pre[i] = tot; }
-            const float incl = row_scan16(tot);
-            const float base = dpp_f32<0x111, 0xF, 0xF, true>(incl);
-            const float T = dpp_f32<0x15F, 0xF, 0xF, true>(incl);
-            const float tgt = uf * T;
-            const float mg = fmaf(DRAW_EPS32, T, 1.0e-37f);
-            float dprev = base - tgt;
-            float fprev = __builtin_amdgcn_fmed3f(dprev * BIG, 0.0f, 1.0f);
-            float dmin = fabsf(dprev);
-#pragma unroll
-            for (int i = 0; i < NPL; i++) {
-                const float cum = (i == NPL - 1) ? incl : base + pre[i];
-                const float dd = cum - tgt;
-                const float f = __builtin_amdgcn_fmed3f(dd * BIG, 0.0f, 1.0f);
-                dmin = fminf(dmin, fabsf(dd));
-                const float sel = f - fprev;
-                fprev = f;
-                kf[i] += sel;
-                if (d & 1) pk2[i] += ((unsigned)sel) << sh; else pk[i] += ((unsigned)sel) << sh;
-            }
-            slack = fminf(slack, dmin - mg);
-            qq = (qq + 1 == Q) ? 0 : qq + 1;
-        }
-        if (__ballot(!(slack >= 0.0f)) == 0ull) {
-            if (row == 0) {
-#pragma unroll
-                for (int i = 0; i < NPL; i++)
-#pragma unroll
-                    for (int b = 0; b < KMAX - 1; b++) cnt[i][b] += ((pk[i] >> (4 * b)) & 15u) + ((pk2[i] >> (4 * b)) & 15u);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NPL; i++) kf[i] = kf1[i];
-            careful_draws(t_begin, count, q_begin);
-        }
-    };
-
-    // staging of the uniform stream: UB values at a time as fp32 in LDS
-    auto refill_u = [&](int base_t) __attribute__((always_inline)) {
-        double v[UB / 64];
-#pragma unroll
-        for (int k = 0; k < UB / 64; k++) v[k] = Ustream[base_t + k * 64 + lane];     // the stream is padded by UB entries
-#pragma unroll
-        for (int k = 0; k < UB / 64; k++) ubuf[k * 64 + lane] = (float)v[k];
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    const int full = (any_flag || Q < 4 * BB) ? 0 : total / (4 * BB);   // speculative blocks
-    int t = 0, q = 0;
-    // operands of the NEXT batch (software pipeline, one batch ahead); qn/tn are wave-uniform
-    float Ln[NPL];
-    float ufn = 0.0f;
-    unsigned shn = 0;
-    int qn = 0, tn = 0;
-    auto prefetch = [&]() __attribute__((always_inline)) {
-        const int ro = qn * stride + lane_row_off;
-#pragma unroll
-        for (int i = 0; i < NPL; i++) Ln[i] = ld_row(ro + i);
-        shn = qcode_lds[qn + row];
-        ufn = ubuf[(tn & (UB - 1)) + row];
-    };
-    if (full > 0) { refill_u(0); prefetch(); }
-    unsigned pkacc[NPL];                                     // committed history, unpacked every 3 blocks
-#pragma unroll
-    for (int i = 0; i < NPL; i++) pkacc[i] = 0;
-    int pending = 0;
-#pragma unroll 1
-    for (int blk = 0; blk < full; blk++) {
-        float kf0[NPL];
-        unsigned pk[NPL];
-#pragma unroll
-        for (int i = 0; i < NPL; i++) { kf0[i] = kf[i]; pk[i] = 0; }
-        float slack = 1.0e30f;                               // min over the block of (distance to a boundary - margin)
-#pragma unroll 1
-        for (int b = 0; b < BB; b++) {
-            float L[NPL];
-#pragma unroll
-            for (int i = 0; i < NPL; i++) L[i] = Ln[i];
-            const unsigned sh = shn;                         // 4*min(symbol, KMAX-1) of this row's draw
-            const float uf = ufn;
-            // advance to the next batch and issue its loads now
-            qn += 4; qn -= (qn >= Q) ? Q : 0;
-            tn += 4;
-            if (b == BB - 1 && (tn & (UB - 1)) == 0) refill_u(tn);    // next batch opens a new window of uniforms
-            prefetch();
-
-            float pre[NPL], tot = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NPL; i++) { tot += (a0f[i] + kf[i]) * L[i]; pre[i] = tot; }
-            const float incl = row_scan16(tot);
-            const float base = dpp_f32<0x111, 0xF, 0xF, true>(incl);            // previous lane of the row, 0 for col 0
-            const float T = dpp_f32<0x15F, 0xF, 0xF, true>(incl);               // row_newbcast:15
-            const float tgt = uf * T;
-            const float mg = fmaf(DRAW_EPS32, T, mg_add);
-            // f(x) = 1 if x >= tgt else 0 without compares: clamp((x - tgt) * BIG) to [0, 1]
-            float dprev = base - tgt;
-            float fprev = __builtin_amdgcn_fmed3f(dprev * BIG, 0.0f, 1.0f);
-            float dmin = fabsf(dprev);
-            unsigned word = 0;
-#pragma unroll
-            for (int i = 0; i < NPL; i++) {
-                const float cum = (i == NPL - 1) ? incl : base + pre[i];
-                const float d = cum - tgt;
-                const float f = __builtin_amdgcn_fmed3f(d * BIG, 0.0f, 1.0f);
-                dmin = fminf(dmin, fabsf(d));
-                const float sel = f - fprev;
-                fprev = f;
-                if (NPL == 1) {
-                    kf[0] += rows_sum4(sel);
-                    pk[0] += ((unsigned)sel) << sh;
-                } else {
-                    word = __builtin_amdgcn_cvt_pk_u8_f32(sel, i, word);
-                }
-            }
-            if (NPL > 1) {
-                uint2v r1 = __builtin_amdgcn_permlane16_swap(word, word, false, false);
-                const unsigned y = r1[0] + r1[1];
-                uint2v r2 = __builtin_amdgcn_permlane32_swap(y, y, false, false);
-                const unsigned wsum = r2[0] + r2[1];
-#pragma unroll
-                for (int i = 0; i < NPL; i++) {
-                    kf[i] += (float)((wsum >> (8 * i)) & 0xFFu);
-                    pk[i] += ((word >> (8 * i)) & 0xFFu) << sh;
-                }
-            }
-            slack = fminf(slack, dmin - mg);
-        }
-        if (__ballot(!(slack >= 0.0f)) == 0ull) {
-#pragma unroll
-            for (int i = 0; i < NPL; i++) pkacc[i] += pk[i];                    // fields <= 4 per block
-            if (++pending == 3) {
-                pending = 0;
-#pragma unroll
-                for (int i = 0; i < NPL; i++) {
-#pragma unroll
-                    for (int b = 0; b < KMAX - 1; b++) cnt[i][b] += (pkacc[i] >> (4 * b)) & 15u;
-                    pkacc[i] = 0;
-                }
-            }
-        } else {
-            n_redo++;
-#pragma unroll
-            for (int i = 0; i < NPL; i++) kf[i] = kf0[i];
-            const unsigned long long r0 = clock64();
-            replay_draws(t, 4 * BB, q);
-            redo_cycles += clock64() - r0;
-        }
-        t += 4 * BB;
-        q += 4 * BB;
-        q -= (q >= Q) ? Q : 0;
-    }
-#pragma unroll
-    for (int i = 0; i < NPL; i++)
-#pragma unroll
-        for (int b = 0; b < KMAX - 1; b++) cnt[i][b] += (pkacc[i] >> (4 * b)) & 15u;
-    q = (int)((long)t % Q);
-    while (t < total) {                                      // tail (and everything, if a slot is flagged)
-        const int count = (total - t < 64) ? (total - t) : 64;
-        careful_draws(t, count, q);
-        t += count;
-        q += count;
-        q = q >= Q ? q % Q : q;
-    }
-
-    // results: counts of all rows are summed through LDS
-#pragma unroll
-    for (int i = 0; i < NPL; i++) {
-        const int s = col * NPL + i;
-        if (s < S) {
-            if (row == 0) R->abund[s] = a0[i] + (double)kf[i];
-#pragma unroll
-            for (int b = 0; b < KMAX; b++) if (cnt[i][b]) atomicAdd(&s_cnt[s * KMAX + b], cnt[i][b]);
-        }
-    }
-    if (lane == 0) {
-        R->n_draws = (unsigned long long)total; R->n_exact = n_exact; R->n_slow = n_slow; R->n_redo = n_redo;
-        R->n_careful = n_careful;
-        R->chain_cycles = clock64() - clk0; R->chain_wall = wall_clock64() - wall0; R->redo_cycles = redo_cycles;
-    }
-}
-
 // --------------------------------------------------------------------------
 // Wide urn chain: a sliding window of 64 draws over the four wavefronts of the
 // workgroup (one per SIMD), four lanes per draw.
@@ -693,6 +227,7 @@ __device__ __forceinline__ void urn_chain_g4(const JobDev& job, const LevelParam
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef int i4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float fma_rn(float a, float b, float c) {       // three-address FMA (no v_fmac + copy)
     float d;
@@ -720,10 +255,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 constexpr int UWIN = 1024;     // uniforms staged in LDS (fp32), refilled in halves
 
-template <int NQ, bool ROWS_LDS>
+template <int NQ, bool ROWS_LDS, int NW>
 __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
-                                            const int* s_slot, volatile double* s_a, volatile double* s_p, float* s_kf,
-                                            const float* s_a0f, int* s_x, float* s_uwin, const float* rows_lds, int stride, int tid) {
+                                            const int* s_slot, volatile double* s_a, volatile double* s_p, unsigned* s_kf,
+                                            const float* s_a0f, unsigned* s_cnt, int* s_x, float* s_uwin, const float* rows_lds, int stride, int tid) {
     constexpr int SPL = 4 * NQ, SP = 16 * NQ;               // strains per lane, capacity
     constexpr int NPLC = SP > 64 ? 2 : 1;                  // strains per lane in the checked tier
     constexpr float EPSW = (float)(SP + 12) * 1.5e-7f;
@@ -736,14 +271,13 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
     const SC_GLOBAL double* Ustream = (const SC_GLOBAL double*)job.U;
     const SC_GLOBAL float* Uf = (const SC_GLOBAL float*)job.Uf;
     const SC_GLOBAL float* rows_g = (const SC_GLOBAL float*)job.tabLf;
-    SC_GLOBAL uint8_t* rec = (SC_GLOBAL uint8_t*)job.rec;
     auto ld4 = [&](int idx) __attribute__((always_inline)) -> f4v {
         return ROWS_LDS ? *(const f4v*)(rows_lds + idx) : *(const SC_GLOBAL f4v*)(rows_g + idx);
     };
     auto ld1 = [&](int idx) __attribute__((always_inline)) -> float { return ROWS_LDS ? rows_lds[idx] : rows_g[idx]; };
 
     const int cbase = k * SPL;                              // first strain of this lane's quarter
-    const float m0 = k > 0 ? 1.0f : 0.0f, m1 = k > 1 ? 1.0f : 0.0f, m2 = k > 2 ? 1.0f : 0.0f;
+    const float m0 = k > 0 ? 1.0f : 0.0f, m1 = k > 1 ? 1.0f : 0.0f;
     const float posf = (float)pos + 1.0e-37f;
     double a0m[NPLC];                                       // wave 0, checked tier: strains across the lanes
 #pragma unroll
@@ -753,6 +287,16 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
     for (int g = 0; g < NQ; g++) a0q[g] = *(const f4v*)(s_a0f + cbase + 4 * g);
     unsigned long long n_exact = 0, n_slow = 0, n_pass = 0;
     const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
+#ifdef SC_PHASE_TIMING
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tph = 0;
+#define SC_PH0 tph = clock64();
+#define SC_PH(i) { const unsigned long long now_ = clock64(); ph[i] += now_ - tph; tph = now_; }
+#define SC_PHW(i) { __builtin_amdgcn_s_waitcnt(0xC07F); SC_PH(i) }
+#else
+#define SC_PH0
+#define SC_PH(i)
+#define SC_PHW(i)
+#endif
 
     // uniforms: draws [ulo, ulo + UWIN) live in s_uwin[p & (UWIN-1)]; wave 0 refills
     int ulo = 0;
@@ -770,10 +314,12 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
     int upos = pos;                                        // (t + pos) & (UWIN - 1)
     f4v L[NQ];
     float uf = 0.0f, llast = 0.0f;
+    int sym = 0;                                           // read symbol of this lane's draw (kept behind the row)
     auto issue_loads = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int g = 0; g < NQ; g++) L[g] = ld4(ro + cbase + 4 * g);
         llast = ld1(ro + Sm1);
+        sym = __float_as_int(ld1(ro + S));
         uf = s_uwin[upos];
     };
     if (total > 0) issue_loads();
@@ -781,22 +327,26 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
     while (t < total) {
         asm volatile("" ::: "memory");                      // s_kf below must be re-read
         n_pass++;
+        SC_PH0
         // this lane's quarter: cumulative weights with the counts in front of draw t
         float loc[SPL];
         float run = 0.0f;
 #pragma unroll
         for (int g = 0; g < NQ; g++) {
-            const f4v av = a0q[g] + *(const f4v*)(s_kf + cbase + 4 * g);
+            const u4v kk = *(const u4v*)(s_kf + cbase + 4 * g);
+            const f4v av = a0q[g] + f4v{(float)kk.x, (float)kk.y, (float)kk.z, (float)kk.w};
             loc[4 * g + 0] = run = (g == 0) ? av.x * L[g].x : fma_rn(av.x, L[g].x, run);
             loc[4 * g + 1] = run = fma_rn(av.y, L[g].y, run);
             loc[4 * g + 2] = run = fma_rn(av.z, L[g].z, run);
             loc[4 * g + 3] = run = fma_rn(av.w, L[g].w, run);
         }
-        const float alast = s_a0f[Sm1] + s_kf[Sm1];
+        const float alast = s_a0f[Sm1] + (float)s_kf[Sm1];
+        SC_PHW(0)
         // quad: offset of this quarter and the total weight (bitwise the same in the four lanes)
-        const float off = fmaf(quad_f32<0xAA>(run), m2, fmaf(quad_f32<0x55>(run), m1, quad_f32<0x00>(run) * m0));
-        const float h = run + quad_f32<0xB1>(run);
-        const float T = h + quad_f32<0x4E>(h);
+        const float i1 = fmaf(quad_f32<0x90>(run), m0, run);       // + previous lane of the quad   ([0,0,1,2])
+        const float i2 = fmaf(quad_f32<0x40>(i1), m1, i1);         // + two lanes back              ([0,0,0,1])
+        const float off = i2 - run;
+        const float T = quad_f32<0xFF>(i2);
         // position of u*T among the boundaries and the distance to the nearest one
         const float tgt = uf * T;
         const float tb = tgt - off;
@@ -811,34 +361,39 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
             w = __builtin_amdgcn_alignbit(w, __float_as_uint(d.y), 31);
             dm = min3_abs(dm, d.x, d.y);
         }
-        int c = __popc(w);
-        c += quad_i32<0xB1>(c);
-        c += quad_i32<0x4E>(c);
-        dm = fminf(dm, quad_f32<0xB1>(dm));
-        dm = fminf(dm, quad_f32<0x4E>(dm));
         // Strains >= S-1 and the padding all sit at cum = T >= u*T.  They never count (a padding entry
         // can round to a tiny negative difference: the count is clamped), and their distance T - u*T
         // must not enter the margin test: alt = -(cum_{S-2} - u*T) is <= 0 while a real boundary lies
         // at or above u*T and is the distance to the nearest real boundary when none does.
-        c = min(c, Sm1);
+        // (max(min_k dm_k, alt) >= lim  <=>  every lane k of the quad has max(dm_k, alt) >= lim.)
         const float alt = tgt - (T - alast * llast);
         const float dmin = fmaxf(dm, alt);
         const float lim = fmaf(EPSW, T, posf);              // NaN (flagged slot) and T == 0 fail the test
+        SC_PH(1)
         const unsigned long long F = ~__ballot(dmin >= lim);
-        const int fpos = F ? 16 * wv + ((int)__builtin_ctzll(F) >> 2) : 64;
+        const int fpos = F ? 16 * wv + ((int)__builtin_ctzll(F) >> 2) : 16 * NW;
         if (lane == 0) s_x[wv] = fpos;
+        int c = __popc(w);
+        c += quad_i32<0xB1>(c);
+        c += quad_i32<0x4E>(c);
+        c = min(c, Sm1);
         lds_barrier();
-        const i4v xf = *(const i4v*)s_x;
         const int rem = total - t;
-        int adv = min(min(xf.x, xf.y), min(xf.z, xf.w));
+        int adv = 16 * NW;
+#pragma unroll
+        for (int j = 0; j < NW / 4; j++) {
+            const i4v xf = *(const i4v*)(s_x + 4 * j);
+            adv = min(adv, min(min(xf.x, xf.y), min(xf.z, xf.w)));
+        }
         adv = adv < rem ? adv : rem;
+        SC_PH(2)
         if (adv == 0) {
             // draw t itself: fp64 scan with the exact counts, then the literal tier (wave 0)
             if (wv == 0) {
                 const double u = Ustream[t];
                 double ad[NPLC];
 #pragma unroll
-                for (int i = 0; i < NPLC; i++) { const int s = lane * NPLC + i; ad[i] = a0m[i] + (double)((s < S) ? s_kf[s] : 0.0f); }
+                for (int i = 0; i < NPLC; i++) { const int s = lane * NPLC + i; ad[i] = a0m[i] + (double)((s < S) ? s_kf[s] : 0u); }
                 const int qi = __builtin_amdgcn_readfirstlane(ro) / stride;
                 const int cc = slow_draw<NPLC>(sa, s_slot, s_a, s_p, ad[0], NPLC > 1 ? ad[NPLC - 1] : 0.0, S, qi, e0, u, lane);
                 n_slow++;
@@ -848,13 +403,15 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
             adv = 1;
         }
         const bool acc = (pos < adv) && (k == 0);
-        if (acc) rec[t + pos] = (uint8_t)c;
+        const int cs = c * KMAX + sym;                       // draws per (strain, read symbol): the substitution counts of :198-206
+        const bool accs = acc && (sym < KMAX);
         t += adv;
         if (t >= total) {
-            if (acc) __hip_atomic_fetch_add(&s_kf[c], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (acc) __hip_atomic_fetch_add(&s_kf[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (accs) __hip_atomic_fetch_add(&s_cnt[cs], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
         }
-        if (Q >= 64) {
+        if (Q >= 16 * NW) {
             const unsigned r1 = (unsigned)(ro + adv * stride);
             const unsigned r2 = r1 - (unsigned)wrap;         // wraps to a huge value while r1 < wrap
             ro = (int)(r1 < r2 ? r1 : r2);
@@ -877,8 +434,11 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
             }
         }
         issue_loads();                                       // rows of the new window first, then the commit
-        if (acc) __hip_atomic_fetch_add(&s_kf[c], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (acc) __hip_atomic_fetch_add(&s_kf[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (accs) __hip_atomic_fetch_add(&s_cnt[cs], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        SC_PH(3)
         lds_barrier();                                       // every wave's commits are in s_kf
+        SC_PH(4)
     }
     __syncthreads();
     if (wv == 0) {
@@ -891,8 +451,14 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
             R->n_draws = (unsigned long long)total; R->n_exact = n_exact; R->n_slow = n_slow; R->n_redo = n_pass;
             R->n_careful = n_slow;
             R->chain_cycles = clock64() - clk0; R->chain_wall = wall_clock64() - wall0; R->redo_cycles = 0;
+#ifdef SC_PHASE_TIMING
+            for (int i = 0; i < 6; i++) R->phase[i] = ph[i];
+#endif
         }
     }
+#undef SC_PH0
+#undef SC_PH
+#undef SC_PHW
 }
 
 // --------------------------------------------------------------------------
@@ -1149,87 +715,26 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
 // --------------------------------------------------------------------------
 // a14 / a18: the urn sampler of one level, np_bayes_clustering
 // (NonparametricClustering.cpp:128-244) and read_assign (:776-836).  One
-// workgroup: all threads turn the log-likelihood table into weight rows
-// L[q][s] = exp(ll - max_s ll) (fp32, in LDS when they fit), then one wavefront
-// runs the chain.  VARIANT: 1, 2, 4 = strains per lane of the grouped chain
-// (S <= 16, 32, 64); 0 = two strains per lane over 64 lanes (S <= 128).
-template <int VARIANT, bool ROWS_LDS>
-__global__ __launch_bounds__(256) void k_chain(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    double* s_a = reinterpret_cast<double*>(s_raw);              // [MAXS]
-    double* s_p = s_a + MAXS;                                    // [MAXS]
-    unsigned* s_cnt = reinterpret_cast<unsigned*>(s_p + MAXS);   // [MAXS*KMAX]
-    int* s_slot = reinterpret_cast<int*>(s_cnt + MAXS * KMAX);   // [MAXS]
-    unsigned char* s_big = s_raw + LDS_SMALL;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int S = P->S, Q = P->Q;
-    constexpr int SPAD = (VARIANT == 0) ? 128 : 64;
-    // VARIANT != 0: [read symbols: Q bytes, rounded][uniform window 4 KB][fp32 rows]; VARIANT 0: [record][rows]
-    const int qpad = (Q + 3 + 15) & ~15;
-    unsigned char* s_qcode = s_big;
-    unsigned char* s_rec = s_big;
-    float* s_ubuf = reinterpret_cast<float*>(s_big + qpad);
-    float* s_rows = (VARIANT == 0) ? reinterpret_cast<float*>(s_big + LDS_REC) : reinterpret_cast<float*>(s_big + qpad + LDS_UBUF);
-    __shared__ int s_anyflag;
-    for (int i = tid; i < MAXS * KMAX; i += nt) s_cnt[i] = 0;
-    if (tid < S) s_slot[tid] = P->slot[tid];
-    if (tid == 0) s_anyflag = 0;
-    __syncthreads();
-    if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_redo = 0; R->chain_cycles = 0; R->chain_wall = 0; }
-    constexpr int WRAP = (VARIANT == 0) ? 0 : 3;     // slots 0..2 are repeated after the last one (grouped chain)
-    for (int qx = tid; qx < Q + WRAP; qx += nt) {
-        const int q = qx < Q ? qx : (qx - Q) % Q;
-        double m = -INFINITY;
-        for (int s = 0; s < S; s++) m = fmax(m, job.tabA[(long)s * job.qcap + q]);
-        const bool flag = !(m >= -600.0);                 // underflow range of the reference's exp(); also NaN / -inf
-        if (qx < Q) {
-            job.qflag[q] = flag ? 1 : 0;
-            job.qmax[q] = m;
-            if (flag) atomicOr(&s_anyflag, 1);
-        }
-        if (VARIANT != 0) { const int c0 = job.qcode[q]; s_qcode[qx] = (unsigned char)(4 * (c0 < KMAX - 1 ? c0 : KMAX - 1)); }
-        float* Lf = ROWS_LDS ? (s_rows + (long)qx * S) : (job.tabLf + (long)qx * SPAD);
-        for (int s = 0; s < S; s++) {
-            const double v = exp(job.tabA[(long)s * job.qcap + q] - m);
-            Lf[s] = flag ? __int_as_float(0x7fc00000) : (float)v;   // a NaN row sends every draw of the slot to the literal tier
-        }
-        if (!ROWS_LDS) for (int s = S; s < SPAD; s++) Lf[s] = 0.0f;
-    }
-    if (ROWS_LDS && VARIANT != 0) for (int i = tid; i < 64; i += nt) s_rows[(long)(Q + WRAP) * S + i] = 0.0f;   // read by lanes past S
-    __syncthreads();
-    if (tid < 64) {
-        if (VARIANT == 0) urn_chain<2, ROWS_LDS>(job, P, R, s_slot, s_a, s_p, s_rec, s_rows, tid);
-        else urn_chain_g4<(VARIANT == 0 ? 1 : VARIANT), ROWS_LDS>(job, P, R, s_slot, s_a, s_p, s_cnt, s_rows, s_qcode, s_ubuf, s_anyflag, tid);
-    }
-    __syncthreads();
-    // draws per (strain, read symbol): the substitution counts of :198-206
-    if (VARIANT == 0) {
-        const int total = P->n_sweeps * Q;
-        for (int t = tid; t < total; t += nt) {
-            const int code = job.qcode[t % Q];
-            if (code < KMAX) atomicAdd(&s_cnt[(int)s_rec[t] * KMAX + code], 1u);
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < S * KMAX; i += nt) R->cnt[i] = s_cnt[i];
-}
-
-// The same stage with the wide chain (urn_chain_w).  NB = blocks of 16 strains.
+// workgroup of four wavefronts: all threads turn the log-likelihood table into
+// weight rows L[q][s] = exp(ll - max_s ll) (fp32, in LDS when they fit, else in
+// HBM/L2), then run the chain (urn_chain_q).  NB = ceil(S / 16): every lane of a
+// quad owns 4 * NB consecutive strains.
 __host__ __device__ inline int chain_w_stride(int S) {
-    const int s4 = (S + 3) & ~3;
+    const int s4 = (S + 1 + 3) & ~3;                          // S weights + the read symbol
     return (s4 & 4) ? s4 : s4 + 4;                            // 4 * odd
 }
 constexpr int CHAINW_ROWS_BYTES = LDS_BIG - UWIN * 4;
+constexpr int CHAIN_NW = 4;      // wavefronts of the sampler workgroup = window of 16 * CHAIN_NW draws
 template <int NB, bool ROWS_LDS>
-__global__ __launch_bounds__(256) void k_chain_w(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R) {
+__global__ __launch_bounds__(64 * CHAIN_NW) void k_chain_w(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_a = reinterpret_cast<double*>(s_raw);              // [MAXS]
     double* s_p = s_a + MAXS;                                    // [MAXS]
     unsigned* s_cnt = reinterpret_cast<unsigned*>(s_p + MAXS);   // [MAXS*KMAX]
     int* s_slot = reinterpret_cast<int*>(s_cnt + MAXS * KMAX);   // [MAXS]
-    float* s_kf = reinterpret_cast<float*>(s_slot + MAXS);       // [MAXS] draws per strain so far
-    float* s_a0f = s_kf + MAXS;                                  // [MAXS] fp32 copy of the starting weights
-    int* s_x = reinterpret_cast<int*>(s_a0f + MAXS);             // [4] first failing position per wave
+    unsigned* s_kf = reinterpret_cast<unsigned*>(s_slot + MAXS); // [MAXS] draws per strain so far
+    float* s_a0f = reinterpret_cast<float*>(s_kf + MAXS);                                  // [MAXS] fp32 copy of the starting weights
+    int* s_x = reinterpret_cast<int*>(s_a0f + MAXS);             // [CHAIN_NW] first failing position per wave
     float* s_uwin = reinterpret_cast<float*>(s_raw + LDS_SMALL); // [UWIN]
     float* s_rows = s_uwin + UWIN;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1238,7 +743,7 @@ __global__ __launch_bounds__(256) void k_chain_w(JobDev job, const LevelParams* 
     for (int i = tid; i < MAXS * KMAX; i += nt) s_cnt[i] = 0;
     if (tid < MAXS) {
         s_slot[tid] = tid < S ? P->slot[tid] : 0;
-        s_kf[tid] = 0.0f;
+        s_kf[tid] = 0u;
         s_a0f[tid] = tid < S ? (float)P->a0[tid] : 0.0f;
     }
     if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_redo = 0; R->chain_cycles = 0; R->chain_wall = 0; }
@@ -1253,7 +758,10 @@ __global__ __launch_bounds__(256) void k_chain_w(JobDev job, const LevelParams* 
             const double v = exp(job.tabA[(long)s * job.qcap + q] - m);
             Lf[s] = flag ? __int_as_float(0x7fc00000) : (float)v;   // a NaN row sends the draw to the literal tier
         }
-        for (int s = S; s < stride; s++) Lf[s] = 0.0f;
+        // the read symbol rides behind the weights (a tiny denormal under a zero count: no effect on the sums)
+        const int c0 = job.qcode[q];
+        Lf[S] = __int_as_float(c0 < KMAX ? c0 : KMAX);
+        for (int s = S + 1; s < stride; s++) Lf[s] = 0.0f;
     }
     // lanes read whole 16-strain blocks: keep what follows the last row finite
     for (int i = tid; i < 16; i += nt) { float* Lf = ROWS_LDS ? (s_rows + (long)Q * stride) : (job.tabLf + (long)Q * stride); Lf[i] = 0.0f; }
@@ -1261,16 +769,13 @@ __global__ __launch_bounds__(256) void k_chain_w(JobDev job, const LevelParams* 
     const int total = P->n_sweeps * Q;
     if (S < 2) {
         // a single candidate takes every draw (discrete_distribution with one weight)
-        for (int t = tid; t < total; t += nt) job.rec[t] = 0;
+        for (int t = tid; t < total; t += nt) {
+            const int code = job.qcode[t % Q];
+            if (code < KMAX) atomicAdd(&s_cnt[code], 1u);
+        }
         if (tid == 0) { R->abund[0] = P->a0[0] + (double)total; R->n_draws = (unsigned long long)total; }
     } else {
-        urn_chain_q<NB, ROWS_LDS>(job, P, R, s_slot, s_a, s_p, s_kf, s_a0f, s_x, s_uwin, s_rows, stride, tid);
-    }
-    __syncthreads();
-    // draws per (strain, read symbol): the substitution counts of :198-206
-    for (int t = tid; t < total; t += nt) {
-        const int code = job.qcode[t % Q];
-        if (code < KMAX) atomicAdd(&s_cnt[(int)job.rec[t] * KMAX + code], 1u);
+        urn_chain_q<NB, ROWS_LDS, CHAIN_NW>(job, P, R, s_slot, s_a, s_p, s_kf, s_a0f, s_cnt, s_x, s_uwin, s_rows, stride, tid);
     }
     __syncthreads();
     for (int i = tid; i < S * KMAX; i += nt) R->cnt[i] = s_cnt[i];
@@ -1579,19 +1084,12 @@ void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node
 }
 constexpr size_t LEVEL_LDS = LDS_SMALL + sizeof(double) * MAXS * KK;
 constexpr size_t CHAIN_LDS = LDS_TOTAL;
-template <int V, bool L> static int set_chain_attr() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain<V, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
-}
 template <int NB, bool L> static int set_chain_w_attr() {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_w<NB, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
 }
 int init_kernels() {
     int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEVEL_LDS);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msa), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSA_LDS);
-    rc |= set_chain_attr<0, true>(); rc |= set_chain_attr<0, false>();
-    rc |= set_chain_attr<1, true>(); rc |= set_chain_attr<1, false>();
-    rc |= set_chain_attr<2, true>(); rc |= set_chain_attr<2, false>();
-    rc |= set_chain_attr<4, true>(); rc |= set_chain_attr<4, false>();
     rc |= set_chain_w_attr<1, true>(); rc |= set_chain_w_attr<1, false>();
     rc |= set_chain_w_attr<2, true>(); rc |= set_chain_w_attr<2, false>();
     rc |= set_chain_w_attr<3, true>(); rc |= set_chain_w_attr<3, false>();
@@ -1607,31 +1105,15 @@ void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, Level
 }
 // S, Q of the level decide the chain variant and whether the fp32 rows fit in LDS.
 void launch_chain(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int S, int Q) {
-    static const bool old_chain = getenv("SC_CHAIN_OLD") != nullptr;
-    if (!old_chain) {
-        const bool wl = ((long)Q * chain_w_stride(S) + 16) * 4 <= (long)CHAINW_ROWS_BYTES;
-#define SC_CHAINW(NB) case NB: if (wl) hipLaunchKernelGGL((k_chain_w<NB, true>), dim3(1), dim3(256), CHAIN_LDS, st, job, P, R); \
-                               else hipLaunchKernelGGL((k_chain_w<NB, false>), dim3(1), dim3(256), CHAIN_LDS, st, job, P, R); break;
-        switch ((S + 15) / 16) {
-            SC_CHAINW(1) SC_CHAINW(2) SC_CHAINW(3) SC_CHAINW(4) SC_CHAINW(5) SC_CHAINW(6) SC_CHAINW(7)
-            default: if (wl) hipLaunchKernelGGL((k_chain_w<8, true>), dim3(1), dim3(256), CHAIN_LDS, st, job, P, R);
-                     else hipLaunchKernelGGL((k_chain_w<8, false>), dim3(1), dim3(256), CHAIN_LDS, st, job, P, R);
-        }
+    const bool wl = ((long)Q * chain_w_stride(S) + 16) * 4 <= (long)CHAINW_ROWS_BYTES;
+#define SC_CHAINW(NB) case NB: if (wl) hipLaunchKernelGGL((k_chain_w<NB, true>), dim3(1), dim3(64 * CHAIN_NW), CHAIN_LDS, st, job, P, R); \
+                               else hipLaunchKernelGGL((k_chain_w<NB, false>), dim3(1), dim3(64 * CHAIN_NW), CHAIN_LDS, st, job, P, R); break;
+    switch ((S + 15) / 16) {
+        SC_CHAINW(1) SC_CHAINW(2) SC_CHAINW(3) SC_CHAINW(4) SC_CHAINW(5) SC_CHAINW(6) SC_CHAINW(7)
+        default: if (wl) hipLaunchKernelGGL((k_chain_w<8, true>), dim3(1), dim3(64 * CHAIN_NW), CHAIN_LDS, st, job, P, R);
+                 else hipLaunchKernelGGL((k_chain_w<8, false>), dim3(1), dim3(64 * CHAIN_NW), CHAIN_LDS, st, job, P, R);
+    }
 #undef SC_CHAINW
-        return;
-    }
-    const int qpad = (Q + 3 + 15) & ~15;
-    const int variant = S <= 16 ? 1 : (S <= 32 ? 2 : (S <= 64 ? 4 : 0));
-    const long cap = variant == 0 ? LDS_ROWS_FLOATS : (LDS_BIG - qpad - LDS_UBUF) / 4 - 64;
-    const bool lds = cap > 0 && (variant == 0 ? (long)Q * S : (long)(Q + 3) * S) <= cap;
-#define SC_CHAIN(V, L) hipLaunchKernelGGL((k_chain<V, L>), dim3(1), dim3(256), CHAIN_LDS, st, job, P, R)
-    switch (variant) {
-        case 1: if (lds) SC_CHAIN(1, true); else SC_CHAIN(1, false); break;
-        case 2: if (lds) SC_CHAIN(2, true); else SC_CHAIN(2, false); break;
-        case 4: if (lds) SC_CHAIN(4, true); else SC_CHAIN(4, false); break;
-        default: if (lds) SC_CHAIN(0, true); else SC_CHAIN(0, false); break;
-    }
-#undef SC_CHAIN
 }
 void launch_msa(hipStream_t st, const MsaDev& d) { hipLaunchKernelGGL(k_msa, dim3(1), dim3(256), MSA_LDS, st, d); }
 // a5 in four launches; `pool_sorted` receives the class pools in read order.
