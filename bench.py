@@ -145,18 +145,18 @@ def main():
                                    "rambl.py options (-q 0 -D 800 -I 13 -l 70 -t 0.02 -d 0.02 -w 5000)" % (a.reads, a.glen, a.strains),
                        "regions_per_gpu": a.regions, "regions_in_flight_per_gpu": streams,
                        "parallelism": "region-sharded x%d, FASTA gather over RCCL" % world},
-            "roofline": {"bound": "hbm", "kernel": "sc::k_chain<V,L> (urn sampler of one level)", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "sc::k_chain_w<NB,L> (urn sampler of one level)", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_READ * k_copies / max(k_n, 1),
                          "avg_launch_ms": avg_ms, "launches_per_step": k_n / max(a.steps, 1),
-                         "draws_per_s_per_wavefront": draws / (k_ms * 1e-3) if k_ms else 0.0},
+                         "draws_per_s_per_region": draws / (k_ms * 1e-3) if k_ms else 0.0},
             "breakdown_ms_per_step": {"graph_host": sum(s["graph_ms"] for s in all_stats) / a.steps,
                                       "level_walk": sum(s["cluster_ms"] for s in all_stats) / a.steps,
                                       "sampler_kernels": k_ms / a.steps,
                                       "draws": draws / a.steps,
                                       "slow_tier_draws": sum(s["slow_draws"] for s in all_stats) / a.steps,
                                       "exact_draws": sum(s["exact_draws"] for s in all_stats) / a.steps,
-                                      "redo_blocks": sum(s["redo_blocks"] for s in all_stats) / a.steps,
+                                      "chain_passes": sum(s["chain_passes"] for s in all_stats) / a.steps,
                                       "chain_cycles_per_draw": sum(s["chain_cycles"] for s in all_stats) / max(draws, 1),
                                       "chain_ns_per_draw": 10.0 * sum(s["chain_wall_ticks"] for s in all_stats) / max(draws, 1),
                                       "avg_candidates_per_sampler_launch": sum(s["sampler_strains"] for s in all_stats) / max(k_n, 1)},

@@ -67,7 +67,7 @@ typedef struct sc_stats {
     long slow_draws;          /* of which needed the fp64 scan tier */
     long exact_draws;         /* of which resolved by the literal fp64 path */
     long sampler_strains;     /* sum over SAMPLE launches of the candidate count */
-    long redo_blocks;         /* 32-draw blocks replayed through the checked tiers */
+    long chain_passes;        /* window passes of the sampler chain (draws / passes = draws accepted per pass) */
     long chain_cycles;        /* shader cycles spent inside the urn chains */
     long chain_wall_ticks;    /* the same in 100 MHz ticks */
     long msa_calls;

@@ -449,7 +449,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     bool branching = false;
     std::vector<std::pair<int, int>> pending_copies;     // (src slot, dst slot) for the next launch
     double sampler_ms = 0;
-    long sampler_launches = 0, level_launches = 0, draws = 0, exact = 0, slow = 0, sampler_copies = 0, sampler_strains = 0, redo = 0;
+    long sampler_launches = 0, level_launches = 0, draws = 0, exact = 0, slow = 0, sampler_copies = 0, sampler_strains = 0, passes = 0;
     unsigned long long chain_cycles = 0, chain_wall = 0;
 
     FILE* level_log = getenv("SC_LEVEL_LOG") ? fopen(getenv("SC_LEVEL_LOG"), "a") : nullptr;   // diagnostics only
@@ -490,17 +490,14 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         level_launches++;
         if (chain) {
             sampler_launches++; sampler_copies += Q;
-            draws += (long)Rh->n_draws; exact += (long)Rh->n_exact; slow += (long)Rh->n_slow; sampler_strains += S; redo += (long)Rh->n_redo;
+            draws += (long)Rh->n_draws; exact += (long)Rh->n_exact; slow += (long)Rh->n_slow; sampler_strains += S; passes += (long)Rh->n_pass;
             chain_cycles += Rh->chain_cycles; chain_wall += Rh->chain_wall;
         }
         if (timed) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
-            if (level_log) fprintf(level_log, "S %d Q %d n %d ms %.4f redo %llu careful %llu slow %llu cyc %llu redocyc %llu ph %llu %llu %llu %llu %llu\n", S, Q, n_sweeps, ms,
-                                   (unsigned long long)Rh->n_redo, (unsigned long long)Rh->n_careful, (unsigned long long)Rh->n_slow,
-                                   (unsigned long long)Rh->chain_cycles, (unsigned long long)Rh->redo_cycles,
-                                   (unsigned long long)Rh->phase[0], (unsigned long long)Rh->phase[1], (unsigned long long)Rh->phase[2],
-                                   (unsigned long long)Rh->phase[3], (unsigned long long)Rh->phase[4]);
+            if (level_log) fprintf(level_log, "S %d Q %d n %d ms %.4f passes %llu slow %llu cyc %llu\n", S, Q, n_sweeps, ms,
+                                   (unsigned long long)Rh->n_pass, (unsigned long long)Rh->n_slow, (unsigned long long)Rh->chain_cycles);
             sampler_ms += ms;
         }
     };
@@ -721,7 +718,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     job.stats.draws = draws;
     job.stats.exact_draws = exact;
     job.stats.slow_draws = slow;
-    job.stats.redo_blocks = redo;
+    job.stats.chain_passes = passes;
     job.stats.chain_cycles = (long)chain_cycles;
     job.stats.chain_wall_ticks = (long)chain_wall;
     job.stats.sampler_strains = sampler_strains;

@@ -72,13 +72,10 @@ struct LevelResult {
     double subst[MAXS * KK];     // HARD: responsibility-weighted substitution counts
     unsigned cnt[MAXS * KMAX];   // SAMPLE: draws per (strain, read symbol)
     unsigned long long n_draws;
-    unsigned long long n_slow;   // draws that needed the fp64 scan tier
-    unsigned long long n_redo;   // 16-draw blocks replayed one draw at a time
-    unsigned long long n_careful;   // draws that went through the per-draw checked path
-    unsigned long long redo_cycles;  // shader cycles spent replaying flagged blocks
+    unsigned long long n_slow;   // draws that went through the fp64 scan tier
+    unsigned long long n_pass;   // window passes of the sampler chain
     unsigned long long chain_cycles, chain_wall;   // shader cycles / 100 MHz ticks spent in the urn chain
     unsigned long long n_exact;  // draws resolved by the literal fp64 path
-    unsigned long long phase[6]; // diagnostics (SC_PHASE_TIMING builds): shader cycles per phase of the wide chain
     int error;
 };
 

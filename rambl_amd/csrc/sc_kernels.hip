@@ -287,16 +287,6 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
     for (int g = 0; g < NQ; g++) a0q[g] = *(const f4v*)(s_a0f + cbase + 4 * g);
     unsigned long long n_exact = 0, n_slow = 0, n_pass = 0;
     const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
-#ifdef SC_PHASE_TIMING
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tph = 0;
-#define SC_PH0 tph = clock64();
-#define SC_PH(i) { const unsigned long long now_ = clock64(); ph[i] += now_ - tph; tph = now_; }
-#define SC_PHW(i) { __builtin_amdgcn_s_waitcnt(0xC07F); SC_PH(i) }
-#else
-#define SC_PH0
-#define SC_PH(i)
-#define SC_PHW(i)
-#endif
 
     // uniforms: draws [ulo, ulo + UWIN) live in s_uwin[p & (UWIN-1)]; wave 0 refills
     int ulo = 0;
@@ -327,7 +317,6 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
     while (t < total) {
         asm volatile("" ::: "memory");                      // s_kf below must be re-read
         n_pass++;
-        SC_PH0
         // this lane's quarter: cumulative weights with the counts in front of draw t
         float loc[SPL];
         float run = 0.0f;
@@ -341,7 +330,6 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
             loc[4 * g + 3] = run = fma_rn(av.w, L[g].w, run);
         }
         const float alast = s_a0f[Sm1] + (float)s_kf[Sm1];
-        SC_PHW(0)
         // quad: offset of this quarter and the total weight (bitwise the same in the four lanes)
         const float i1 = fmaf(quad_f32<0x90>(run), m0, run);       // + previous lane of the quad   ([0,0,1,2])
         const float i2 = fmaf(quad_f32<0x40>(i1), m1, i1);         // + two lanes back              ([0,0,0,1])
@@ -369,7 +357,6 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
         const float alt = tgt - (T - alast * llast);
         const float dmin = fmaxf(dm, alt);
         const float lim = fmaf(EPSW, T, posf);              // NaN (flagged slot) and T == 0 fail the test
-        SC_PH(1)
         const unsigned long long F = ~__ballot(dmin >= lim);
         const int fpos = F ? 16 * wv + ((int)__builtin_ctzll(F) >> 2) : 16 * NW;
         if (lane == 0) s_x[wv] = fpos;
@@ -386,7 +373,6 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
             adv = min(adv, min(min(xf.x, xf.y), min(xf.z, xf.w)));
         }
         adv = adv < rem ? adv : rem;
-        SC_PH(2)
         if (adv == 0) {
             // draw t itself: fp64 scan with the exact counts, then the literal tier (wave 0)
             if (wv == 0) {
@@ -436,9 +422,7 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
         issue_loads();                                       // rows of the new window first, then the commit
         if (acc) __hip_atomic_fetch_add(&s_kf[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (accs) __hip_atomic_fetch_add(&s_cnt[cs], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        SC_PH(3)
         lds_barrier();                                       // every wave's commits are in s_kf
-        SC_PH(4)
     }
     __syncthreads();
     if (wv == 0) {
@@ -448,17 +432,10 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
             if (s < S) R->abund[s] = a0m[i] + (double)s_kf[s];
         }
         if (lane == 0) {
-            R->n_draws = (unsigned long long)total; R->n_exact = n_exact; R->n_slow = n_slow; R->n_redo = n_pass;
-            R->n_careful = n_slow;
-            R->chain_cycles = clock64() - clk0; R->chain_wall = wall_clock64() - wall0; R->redo_cycles = 0;
-#ifdef SC_PHASE_TIMING
-            for (int i = 0; i < 6; i++) R->phase[i] = ph[i];
-#endif
+            R->n_draws = (unsigned long long)total; R->n_exact = n_exact; R->n_slow = n_slow; R->n_pass = n_pass;
+            R->chain_cycles = clock64() - clk0; R->chain_wall = wall_clock64() - wall0;
         }
     }
-#undef SC_PH0
-#undef SC_PH
-#undef SC_PHW
 }
 
 // --------------------------------------------------------------------------
@@ -494,7 +471,7 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
         __syncthreads();                       // a later copy may read this row
     }
     for (int i = tid; i < MAXS * KMAX; i += nt) s_cnt[i] = 0;
-    if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_redo = 0; R->chain_cycles = 0; R->chain_wall = 0; }
+    if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_pass = 0; R->chain_cycles = 0; R->chain_wall = 0; }
     __syncthreads();
 
     // ---- phase 1: read log-likelihood update, NonparametricClustering.cpp:343-391
@@ -724,9 +701,10 @@ __host__ __device__ inline int chain_w_stride(int S) {
     return (s4 & 4) ? s4 : s4 + 4;                            // 4 * odd
 }
 constexpr int CHAINW_ROWS_BYTES = LDS_BIG - UWIN * 4;
-constexpr int CHAIN_NW = 4;      // wavefronts of the sampler workgroup = window of 16 * CHAIN_NW draws
+constexpr int CHAIN_NW = 4;      // wavefronts that run the chain = window of 16 * CHAIN_NW draws
+constexpr int CHAIN_THREADS = 512;   // the extra wavefronts only help to build the weight rows, then leave
 template <int NB, bool ROWS_LDS>
-__global__ __launch_bounds__(64 * CHAIN_NW) void k_chain_w(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R) {
+__global__ __launch_bounds__(CHAIN_THREADS) void k_chain_w(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_a = reinterpret_cast<double*>(s_raw);              // [MAXS]
     double* s_p = s_a + MAXS;                                    // [MAXS]
@@ -737,7 +715,8 @@ __global__ __launch_bounds__(64 * CHAIN_NW) void k_chain_w(JobDev job, const Lev
     int* s_x = reinterpret_cast<int*>(s_a0f + MAXS);             // [CHAIN_NW] first failing position per wave
     float* s_uwin = reinterpret_cast<float*>(s_raw + LDS_SMALL); // [UWIN]
     float* s_rows = s_uwin + UWIN;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x;
+    int nt = blockDim.x;
     const int S = P->S, Q = P->Q;
     const int stride = chain_w_stride(S);
     for (int i = tid; i < MAXS * KMAX; i += nt) s_cnt[i] = 0;
@@ -746,7 +725,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW) void k_chain_w(JobDev job, const Lev
         s_kf[tid] = 0u;
         s_a0f[tid] = tid < S ? (float)P->a0[tid] : 0.0f;
     }
-    if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_redo = 0; R->chain_cycles = 0; R->chain_wall = 0; }
+    if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_pass = 0; R->chain_cycles = 0; R->chain_wall = 0; }
     for (int q = tid; q < Q; q += nt) {
         double m = -INFINITY;
         for (int s = 0; s < S; s++) m = fmax(m, job.tabA[(long)s * job.qcap + q]);
@@ -766,6 +745,8 @@ __global__ __launch_bounds__(64 * CHAIN_NW) void k_chain_w(JobDev job, const Lev
     // lanes read whole 16-strain blocks: keep what follows the last row finite
     for (int i = tid; i < 16; i += nt) { float* Lf = ROWS_LDS ? (s_rows + (long)Q * stride) : (job.tabLf + (long)Q * stride); Lf[i] = 0.0f; }
     __syncthreads();
+    if (tid >= 64 * CHAIN_NW) return;                      // a finished wavefront no longer counts at the barriers below
+    nt = 64 * CHAIN_NW;
     const int total = P->n_sweeps * Q;
     if (S < 2) {
         // a single candidate takes every draw (discrete_distribution with one weight)
@@ -1106,12 +1087,12 @@ void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, Level
 // S, Q of the level decide the chain variant and whether the fp32 rows fit in LDS.
 void launch_chain(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int S, int Q) {
     const bool wl = ((long)Q * chain_w_stride(S) + 16) * 4 <= (long)CHAINW_ROWS_BYTES;
-#define SC_CHAINW(NB) case NB: if (wl) hipLaunchKernelGGL((k_chain_w<NB, true>), dim3(1), dim3(64 * CHAIN_NW), CHAIN_LDS, st, job, P, R); \
-                               else hipLaunchKernelGGL((k_chain_w<NB, false>), dim3(1), dim3(64 * CHAIN_NW), CHAIN_LDS, st, job, P, R); break;
+#define SC_CHAINW(NB) case NB: if (wl) hipLaunchKernelGGL((k_chain_w<NB, true>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, P, R); \
+                               else hipLaunchKernelGGL((k_chain_w<NB, false>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, P, R); break;
     switch ((S + 15) / 16) {
         SC_CHAINW(1) SC_CHAINW(2) SC_CHAINW(3) SC_CHAINW(4) SC_CHAINW(5) SC_CHAINW(6) SC_CHAINW(7)
-        default: if (wl) hipLaunchKernelGGL((k_chain_w<8, true>), dim3(1), dim3(64 * CHAIN_NW), CHAIN_LDS, st, job, P, R);
-                 else hipLaunchKernelGGL((k_chain_w<8, false>), dim3(1), dim3(64 * CHAIN_NW), CHAIN_LDS, st, job, P, R);
+        default: if (wl) hipLaunchKernelGGL((k_chain_w<8, true>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, P, R);
+                 else hipLaunchKernelGGL((k_chain_w<8, false>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, P, R);
     }
 #undef SC_CHAINW
 }
