@@ -36,7 +36,7 @@ namespace sc {
 void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node, const int* pool_ptr, const int* pool_rid,
                          const int* pool_cn, const uint8_t* node_is_end, const int* edge_src, int n_edges, int sorted,
                          int* support);
-void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int do_update);
+void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, const LevelParams& H, int do_update);
 void launch_chain(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int S, int Q);
 void launch_msa(hipStream_t st, const MsaDev& d);
 void launch_thread(hipStream_t st, const ThreadDev& d, int* pool_sorted);
@@ -480,7 +480,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         HIPCHK(hipMemcpyAsync(Pd, Ph, bytes, hipMemcpyHostToDevice, st));
         const bool chain = (mode == MODE_SAMPLE) && S > 1 && n_sweeps > 0;
         const bool timed = chain && pa.want_timing;
-        launch_level(st, jd, Pd, Rd, do_update ? 1 : 0);
+        launch_level(st, jd, Pd, Rd, P, do_update ? 1 : 0);
         if (chain) {
             if (timed) HIPCHK(hipEventRecord(ev0, st));
             launch_chain(st, jd, Pd, Rd, S, Q);

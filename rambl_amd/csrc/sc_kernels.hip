@@ -439,9 +439,72 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
 }
 
 // --------------------------------------------------------------------------
-// One level of the walk for one region.  Single workgroup.
+// Grid-parallel pieces of one level (the usual case: every label a single symbol, no read twice in
+// the level).  They are plain data-parallel loops over (strain, read) items; k_level keeps the
+// order-dependent parts.
+enum { LV_COPIES_DONE = 1, LV_ITEMS_DONE = 2, LV_TABLE_ELSEWHERE = 4 };
+
+// phase 0: rows of strains created by the last extension (Strain copy, Strain.cpp:73-83); copies are
+// independent (a destination row is a free row, a source row a surviving parent's)
+__global__ __launch_bounds__(256) void k_level_copy(JobDev job, const LevelParams* __restrict__ P) {
+    const int c = blockIdx.y;
+    const double2* src = reinterpret_cast<const double2*>(job.ll + (long)P->copy_src[c] * job.ll_stride);
+    double2* dst = reinterpret_cast<double2*>(job.ll + (long)P->copy_dst[c] * job.ll_stride);
+    const int n2 = (job.n_reads + 1) >> 1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// phase 1, single-symbol labels: ll[s][rid] (+)= log P(read symbol | strain symbol), NonparametricClustering.cpp:343-391
+__global__ __launch_bounds__(256) void k_level_update(JobDev job, const LevelParams* __restrict__ P) {
+    __shared__ double s_row[MAXS * KMAX];       // lpt[s][label of s][b]
+    __shared__ double s_diag[MAXS * KMAX];      // lpt[s][b][b]  (an N in the strain label matches the read symbol)
+    __shared__ int s_slot[MAXS], s_lab[MAXS];
+    const int tid = threadIdx.x;
+    const int S = P->S, K = job.K, e0 = P->e0, Rn = P->e1 - P->e0, codeN = job.code_N;
+    for (int s = tid; s < S; s += blockDim.x) { s_slot[s] = P->slot[s]; s_lab[s] = job.labels[P->lab_off[s]]; }
+    __syncthreads();
+    for (int i = tid; i < S * KMAX; i += blockDim.x) {
+        const int sx = i / KMAX, b = i % KMAX, a = s_lab[sx];
+        const double* lp = P->lpt + (long)sx * KK;
+        s_row[i] = (a < KMAX) ? lp[a * KMAX + b] : 0.0;
+        s_diag[i] = lp[b * KMAX + b];
+    }
+    __syncthreads();
+    const long total = (long)S * Rn;
+    const long stride = job.ll_stride;
+    for (long idx = (long)blockIdx.x * blockDim.x + tid; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int sx = (int)(idx / Rn), e = e0 + (int)(idx % Rn);
+        const int rid = job.ent_rid[e];
+        const int b = job.labels[job.ent_lab_off[e]];
+        const bool fresh = job.ent_first[e] && !job.has[rid];
+        int a = s_lab[sx];
+        const bool wild = (a == codeN);
+        if (wild) a = b;
+        const double val = (a < K && b < K) ? (wild ? s_diag[sx * KMAX + b] : s_row[sx * KMAX + b]) : __longlong_as_double(0x7ff8000000000000ll);
+        double* cell = job.ll + (long)s_slot[sx] * stride + rid;
+        *cell = fresh ? val : (*cell + val);               // Strain::update_read_loglik, Strain.cpp:85-95
+    }
+}
+
+// MODE_SAMPLE: the per-slot log-likelihood table tabA[s][q] = ll(read) + ll(mate); k_chain_w draws from it
+__global__ __launch_bounds__(256) void k_level_table(JobDev job, const LevelParams* __restrict__ P) {
+    const int S = P->S, Q = P->Q, e0 = P->e0;
+    const long total = (long)S * Q;
+    const long stride = job.ll_stride;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int sx = (int)(idx / Q), q = (int)(idx % Q);
+        const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
+        const double* row = job.ll + (long)P->slot[sx] * stride;
+        double x = job.has[rid] ? row[rid] : 0.0;
+        if (uid >= 0 && job.has[uid]) x += row[uid];
+        job.tabA[(long)sx * job.qcap + q] = x;
+    }
+}
+
+// --------------------------------------------------------------------------
+// One level of the walk for one region.  Single workgroup.  `done` = LV_* pieces already run on the grid.
 __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
-                                                int do_update) {
+                                                int do_update, int done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_a = reinterpret_cast<double*>(s_raw);              // [MAXS]
     double* s_p = s_a + MAXS;                                    // [MAXS]
@@ -458,7 +521,7 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
     if (tid < S) { s_slot[tid] = P->slot[tid]; s_laboff[tid] = P->lab_off[tid]; s_lablen[tid] = P->lab_len[tid]; s_logpri[tid] = P->logpri[tid]; }
 
     // ---- phase 0: rows of strains created by the last extension (Strain copy, Strain.cpp:73-83)
-    for (int c = 0; c < P->n_copy; c++) {
+    for (int c = 0; c < ((done & LV_COPIES_DONE) ? 0 : P->n_copy); c++) {
         const double2* src = reinterpret_cast<const double2*>(job.ll + (long)P->copy_src[c] * stride);
         double2* dst = reinterpret_cast<double2*>(job.ll + (long)P->copy_dst[c] * stride);
         const int n2 = (job.n_reads + 1) >> 1;
@@ -517,7 +580,9 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
             const bool fresh = job.ent_first[e] && !job.has[rid];
             *cell = fresh ? val : (*cell + val);            // Strain::update_read_loglik, Strain.cpp:85-95
         };
-        if (!P->has_dups && !P->any_multi) {
+        if (done & LV_ITEMS_DONE) {
+            // k_level_update has applied the items
+        } else if (!P->has_dups && !P->any_multi) {
             // single-symbol labels everywhere (the usual level): four items per thread in flight,
             // so the dependent loads entry -> read id -> log-likelihood cell overlap
             const long total = (long)S * Rn;
@@ -661,6 +726,7 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
 
     // ---- MODE_SAMPLE: the per-slot log-likelihood table; k_chain draws from it
     if (P->n_sweeps <= 0 || S == 1) return;           // nothing to draw (host handles S == 1 and n == 0)
+    if (done & LV_TABLE_ELSEWHERE) return;
     {
         const long total = (long)S * Q;
         constexpr int U = 4;
@@ -1081,8 +1147,33 @@ int init_kernels() {
     rc |= set_chain_w_attr<8, true>(); rc |= set_chain_w_attr<8, false>();
     return rc;
 }
-void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int do_update) {
-    hipLaunchKernelGGL(k_level, dim3(1), dim3(512), LEVEL_LDS, st, job, P, R, do_update);
+// One level: the data-parallel pieces on a grid when the level has the usual shape, the rest in k_level.
+void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, const LevelParams& H, int do_update) {
+    const int S = H.S, Rn = H.e1 - H.e0;
+    int done = 0;
+    if (H.n_copy > 0) {
+        const int n2 = (job.n_reads + 1) >> 1;
+        int bx = (n2 + 1023) / 1024;
+        bx = bx < 1 ? 1 : (bx > 32 ? 32 : bx);
+        hipLaunchKernelGGL(k_level_copy, dim3(bx, H.n_copy), dim3(256), 0, st, job, P);
+        done |= LV_COPIES_DONE;
+    }
+    if (do_update && Rn > 0 && S > 0 && !H.has_dups && !H.any_multi) {
+        const long items = (long)S * Rn;
+        int g = (int)((items + 511) / 512);
+        g = g < 1 ? 1 : (g > 128 ? 128 : g);
+        hipLaunchKernelGGL(k_level_update, dim3(g), dim3(256), 0, st, job, P);
+        done |= LV_ITEMS_DONE;
+    }
+    const bool table = H.mode == MODE_SAMPLE && H.n_sweeps > 0 && S > 1 && Rn > 0;
+    if (table) done |= LV_TABLE_ELSEWHERE;
+    hipLaunchKernelGGL(k_level, dim3(1), dim3(512), LEVEL_LDS, st, job, P, R, do_update, done);
+    if (table) {
+        const long items = (long)S * H.Q;
+        int g = (int)((items + 511) / 512);
+        g = g < 1 ? 1 : (g > 128 ? 128 : g);
+        hipLaunchKernelGGL(k_level_table, dim3(g), dim3(256), 0, st, job, P);
+    }
 }
 // S, Q of the level decide the chain variant and whether the fp32 rows fit in LDS.
 void launch_chain(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int S, int Q) {
