@@ -4,7 +4,7 @@
 A step = one pass of the path (graph build + level walk with its HIP kernels +
 read_assign) over one region: BASELINE.json configs[1], 10 000 synthetic 150 bp
 reads against one 1 500 bp gene (seed 21).  With N > 1 ranks every rank runs a
-region of the same shape (seed 21 + rank: weak scaling), nothing is exchanged
+region of the same shape and seed (weak scaling), nothing is exchanged
 while regions run, and the step ends with the RCCL gather of the FASTA bytes to
 rank 0.  Prints ONE JSON line on rank 0.
 """
@@ -84,7 +84,7 @@ def main():
     d = tempfile.mkdtemp(prefix="scbench_%d_" % rank)
     prepared = []
     for k in range(a.regions):
-        seed = 21 + rank * a.regions + k
+        seed = 21 + k                                    # the same regions on every rank: per-GPU work is fixed (weak scaling)
         gene = synth.make_gene(seed, glen=a.glen, n_strains=a.strains, n_reads=a.reads, name="gene%d" % seed)
         fasta, sam = synth.write_dataset(os.path.join(d, "r%d" % k), [gene])
         roi = "%s:1-%d" % (gene["name"], a.glen)
@@ -92,7 +92,7 @@ def main():
         prepared.append((pa, cli.load_regions(pa)))      # host ingest, outside the timed region
     pa, regions = prepared[0]
     fasta, sam = pa.gene_file, pa.mapping_file
-    gene = {"name": "gene%d" % (21 + rank * a.regions)}
+    gene = {"name": "gene21"}
     params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate), want_timing=True)
     ctx = capi.Context(local, streams)
 
@@ -141,7 +141,7 @@ def main():
             "metric": "reads/sec into POA (150bp, ~1.5k-node graph)", "value": total_reads / dt, "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d x 150bp reads vs one %dbp gene, %d strains, seed 21(+rank), "
+            "config": {"workload": "configs[1]: %d x 150bp reads vs one %dbp gene, %d strains, seed 21, "
                                    "rambl.py options (-q 0 -D 800 -I 13 -l 70 -t 0.02 -d 0.02 -w 5000)" % (a.reads, a.glen, a.strains),
                        "regions_per_gpu": a.regions, "regions_in_flight_per_gpu": streams,
                        "parallelism": "region-sharded x%d, FASTA gather over RCCL" % world},

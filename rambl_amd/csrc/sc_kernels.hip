@@ -477,12 +477,34 @@ __global__ __launch_bounds__(256) void k_level_update(JobDev job, const LevelPar
         const int rid = job.ent_rid[e];
         const int b = job.labels[job.ent_lab_off[e]];
         const bool fresh = job.ent_first[e] && !job.has[rid];
+        if (sx == 0) job.isnew[e - e0] = fresh ? 1 : 0;
         int a = s_lab[sx];
         const bool wild = (a == codeN);
         if (wild) a = b;
         const double val = (a < K && b < K) ? (wild ? s_diag[sx * KMAX + b] : s_row[sx * KMAX + b]) : __longlong_as_double(0x7ff8000000000000ll);
         double* cell = job.ll + (long)s_slot[sx] * stride + rid;
         *cell = fresh ? val : (*cell + val);               // Strain::update_read_loglik, Strain.cpp:85-95
+    }
+}
+
+// after the update: the reads of the level are now present in read_loglik (`has`), and the draw slots
+// q = (entry, copy) of the level; the reference walks copies from cn down to 1 (:161-167)
+__global__ __launch_bounds__(256) void k_level_slots(JobDev job, const LevelParams* __restrict__ P, int do_update) {
+    const int e0 = P->e0, Rn = P->e1 - P->e0;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Rn; r += gridDim.x * blockDim.x) {
+        const int e = e0 + r;
+        const int rid = job.ent_rid[e], cn = job.ent_cn[e];
+        if (do_update) job.has[rid] = 1;
+        const int qb = job.ent_qoff[e];
+        const int mb = job.mate_ptr[rid], mn = job.mate_ptr[rid + 1] - mb;
+        const uint8_t code = (job.ent_lab_len[e] == 1) ? job.labels[job.ent_lab_off[e]] : (uint8_t)0xFF;
+        for (int i = 0; i < cn; i++) {
+            const int k = cn - 1 - i;
+            const int uid = (k < mn) ? job.mate_idx[mb + k] : -1;
+            job.qent[qb + i] = r;
+            job.quid[qb + i] = uid;
+            job.qcode[qb + i] = code;
+        }
     }
 }
 
@@ -543,7 +565,7 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
             const int e = e0 + r;
             job.isnew[r] = (job.ent_first[e] && !job.has[job.ent_rid[e]]) ? 1 : 0;
         }
-        for (int i = tid; i < S * KK; i += nt) s_tab[i] = P->lpt[i];
+        if (!(done & LV_ITEMS_DONE)) for (int i = tid; i < S * KK; i += nt) s_tab[i] = P->lpt[i];
         __syncthreads();
         const int codeN = job.code_N;
         auto item = [&](int s, int r) {
@@ -1166,8 +1188,15 @@ void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, Level
         done |= LV_ITEMS_DONE;
     }
     const bool table = H.mode == MODE_SAMPLE && H.n_sweeps > 0 && S > 1 && Rn > 0;
-    if (table) done |= LV_TABLE_ELSEWHERE;
-    hipLaunchKernelGGL(k_level, dim3(1), dim3(512), LEVEL_LDS, st, job, P, R, do_update, done);
+    if (table && (!do_update || (done & LV_ITEMS_DONE))) {
+        // a sampler level of the usual shape: nothing order-dependent is left for k_level
+        int g = (Rn + 255) / 256;
+        g = g > 64 ? 64 : g;
+        hipLaunchKernelGGL(k_level_slots, dim3(g), dim3(256), 0, st, job, P, do_update);
+    } else {
+        if (table) done |= LV_TABLE_ELSEWHERE;
+        hipLaunchKernelGGL(k_level, dim3(1), dim3(512), LEVEL_LDS, st, job, P, R, do_update, done);
+    }
     if (table) {
         const long items = (long)S * H.Q;
         int g = (int)((items + 511) / 512);
