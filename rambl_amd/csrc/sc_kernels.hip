@@ -789,8 +789,10 @@ __host__ __device__ inline int chain_w_stride(int S) {
     return (s4 & 4) ? s4 : s4 + 4;                            // 4 * odd
 }
 constexpr int CHAINW_ROWS_BYTES = LDS_BIG - UWIN * 4;
-constexpr int CHAIN_NW = 4;      // wavefronts that run the chain = window of 16 * CHAIN_NW draws
-constexpr int CHAIN_THREADS = 512;   // the extra wavefronts only help to build the weight rows, then leave
+constexpr int CHAIN_THREADS = 512;   // eight wavefronts build the weight rows
+// wavefronts that run the chain = window of 16 * NW draws: all eight while a lane's share of the strains is
+// small (the pass is latency-bound and a wider window accepts more draws), four otherwise (the others leave)
+constexpr int chain_nw(int nb) { return nb <= 2 ? 8 : 4; }
 template <int NB, bool ROWS_LDS>
 __global__ __launch_bounds__(CHAIN_THREADS) void k_chain_w(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -800,7 +802,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain_w(JobDev job, const Lev
     int* s_slot = reinterpret_cast<int*>(s_cnt + MAXS * KMAX);   // [MAXS]
     unsigned* s_kf = reinterpret_cast<unsigned*>(s_slot + MAXS); // [MAXS] draws per strain so far
     float* s_a0f = reinterpret_cast<float*>(s_kf + MAXS);                                  // [MAXS] fp32 copy of the starting weights
-    int* s_x = reinterpret_cast<int*>(s_a0f + MAXS);             // [CHAIN_NW] first failing position per wave
+    int* s_x = reinterpret_cast<int*>(s_a0f + MAXS);             // [8] first failing position per wave
     float* s_uwin = reinterpret_cast<float*>(s_raw + LDS_SMALL); // [UWIN]
     float* s_rows = s_uwin + UWIN;
     const int tid = threadIdx.x;
@@ -833,8 +835,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain_w(JobDev job, const Lev
     // lanes read whole 16-strain blocks: keep what follows the last row finite
     for (int i = tid; i < 16; i += nt) { float* Lf = ROWS_LDS ? (s_rows + (long)Q * stride) : (job.tabLf + (long)Q * stride); Lf[i] = 0.0f; }
     __syncthreads();
-    if (tid >= 64 * CHAIN_NW) return;                      // a finished wavefront no longer counts at the barriers below
-    nt = 64 * CHAIN_NW;
+    constexpr int NW = chain_nw(NB);
+    if (tid >= 64 * NW) return;                            // a finished wavefront no longer counts at the barriers below
+    nt = 64 * NW;
     const int total = P->n_sweeps * Q;
     if (S < 2) {
         // a single candidate takes every draw (discrete_distribution with one weight)
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain_w(JobDev job, const Lev
         }
         if (tid == 0) { R->abund[0] = P->a0[0] + (double)total; R->n_draws = (unsigned long long)total; }
     } else {
-        urn_chain_q<NB, ROWS_LDS, CHAIN_NW>(job, P, R, s_slot, s_a, s_p, s_kf, s_a0f, s_cnt, s_x, s_uwin, s_rows, stride, tid);
+        urn_chain_q<NB, ROWS_LDS, NW>(job, P, R, s_slot, s_a, s_p, s_kf, s_a0f, s_cnt, s_x, s_uwin, s_rows, stride, tid);
     }
     __syncthreads();
     for (int i = tid; i < S * KMAX; i += nt) R->cnt[i] = s_cnt[i];
