@@ -442,7 +442,7 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
 // Grid-parallel pieces of one level (the usual case: every label a single symbol, no read twice in
 // the level).  They are plain data-parallel loops over (strain, read) items; k_level keeps the
 // order-dependent parts.
-enum { LV_COPIES_DONE = 1, LV_ITEMS_DONE = 2, LV_TABLE_ELSEWHERE = 4 };
+enum { LV_COPIES_DONE = 1, LV_ITEMS_DONE = 2 };
 
 // phase 0: rows of strains created by the last extension (Strain copy, Strain.cpp:73-83); copies are
 // independent (a destination row is a free row, a source row a surviving parent's)
@@ -508,18 +508,53 @@ __global__ __launch_bounds__(256) void k_level_slots(JobDev job, const LevelPara
     }
 }
 
-// MODE_SAMPLE: the per-slot log-likelihood table tabA[s][q] = ll(read) + ll(mate); k_chain_w draws from it
-__global__ __launch_bounds__(256) void k_level_table(JobDev job, const LevelParams* __restrict__ P) {
+// MODE_SAMPLE: what the sampler draws from.  Per draw slot q: tabA[s][q] = ll(read) + ll(mate) (fp64, for
+// the checked tiers), qmax / qflag, and the fp32 weight row L[q][s] = exp(tabA - max_s) with the read's
+// symbol behind it (layout: chain_w_stride).  G lanes share a slot, each walks S / G strains; the max is
+// joined by shuffles.
+__host__ __device__ inline int chain_w_stride(int S) {
+    const int s4 = (S + 1 + 3) & ~3;                          // S weights + the read symbol
+    return (s4 & 4) ? s4 : s4 + 4;                            // 4 * odd: conflict-free 16-byte row reads
+}
+__global__ __launch_bounds__(256) void k_level_table(JobDev job, const LevelParams* __restrict__ P, int G) {
     const int S = P->S, Q = P->Q, e0 = P->e0;
-    const long total = (long)S * Q;
     const long stride = job.ll_stride;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int sx = (int)(idx / Q), q = (int)(idx % Q);
+    const int wstride = chain_w_stride(S);
+    const int per = (S + G - 1) / G;                         // strains per lane
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = (int)(gid % G);
+    const long q = gid / G;
+    const bool live = q < Q;
+    const int s0 = g * per, s1 = (s0 + per < S) ? s0 + per : S;
+    double m = -INFINITY;
+    if (live) {
         const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
-        const double* row = job.ll + (long)P->slot[sx] * stride;
-        double x = job.has[rid] ? row[rid] : 0.0;
-        if (uid >= 0 && job.has[uid]) x += row[uid];
-        job.tabA[(long)sx * job.qcap + q] = x;
+        const bool hr = job.has[rid] != 0, hu = uid >= 0 && job.has[uid] != 0;
+        for (int sx = s0; sx < s1; sx++) {
+            const double* row = job.ll + (long)P->slot[sx] * stride;
+            double x = hr ? row[rid] : 0.0;
+            if (hu) x += row[uid];
+            job.tabA[(long)sx * job.qcap + q] = x;
+            m = fmax(m, x);
+        }
+    }
+    for (int d = 1; d < G; d <<= 1) m = fmax(m, __shfl_xor(m, d));       // G is a power of two <= 16: lanes of one slot are adjacent
+    if (!live) return;
+    const bool flag = !(m >= -600.0);                        // underflow range of the reference's exp(); also NaN / -inf
+    float* Lf = job.tabLf + q * wstride;
+    for (int sx = s0; sx < s1; sx++) {
+        const double v = exp(job.tabA[(long)sx * job.qcap + q] - m);
+        Lf[sx] = flag ? __int_as_float(0x7fc00000) : (float)v;          // a NaN row sends the draw to the literal tier
+    }
+    if (g == 0) {
+        job.qflag[q] = flag ? 1 : 0;
+        job.qmax[q] = m;
+        // the read symbol rides behind the weights (a tiny denormal under a zero count: no effect on the sums)
+        const int c0 = job.qcode[q];
+        Lf[S] = __int_as_float(c0 < KMAX ? c0 : KMAX);
+        for (int sx = S + 1; sx < wstride; sx++) Lf[sx] = 0.0f;
+        // the chain reads whole 16-strain blocks: keep what follows the last row finite
+        if (q == Q - 1) for (int i = 0; i < 16; i++) Lf[wstride + i] = 0.0f;
     }
 }
 
@@ -746,48 +781,16 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
         return;
     }
 
-    // ---- MODE_SAMPLE: the per-slot log-likelihood table; k_chain draws from it
-    if (P->n_sweeps <= 0 || S == 1) return;           // nothing to draw (host handles S == 1 and n == 0)
-    if (done & LV_TABLE_ELSEWHERE) return;
-    {
-        const long total = (long)S * Q;
-        constexpr int U = 4;
-        for (long base = tid; base < total; base += (long)U * nt) {
-            int sidx[U], qq[U], rid[U], uid[U];
-            bool live[U];
-#pragma unroll
-            for (int k = 0; k < U; k++) {
-                const long idx = base + (long)k * nt;
-                live[k] = idx < total;
-                const long ii = live[k] ? idx : 0;
-                sidx[k] = (int)(ii / Q); qq[k] = (int)(ii % Q);
-                rid[k] = job.ent_rid[e0 + job.qent[qq[k]]];
-                uid[k] = job.quid[qq[k]];
-            }
-            double x[U];
-#pragma unroll
-            for (int k = 0; k < U; k++) {
-                const double* row = job.ll + (long)s_slot[sidx[k]] * stride;
-                x[k] = job.has[rid[k]] ? row[rid[k]] : 0.0;
-                if (uid[k] >= 0 && job.has[uid[k]]) x[k] += row[uid[k]];
-            }
-#pragma unroll
-            for (int k = 0; k < U; k++) if (live[k]) job.tabA[(long)sidx[k] * job.qcap + qq[k]] = x[k];
-        }
-    }
+    // MODE_SAMPLE: k_level_table builds what the sampler draws from
 }
 
 // --------------------------------------------------------------------------
 // a14 / a18: the urn sampler of one level, np_bayes_clustering
 // (NonparametricClustering.cpp:128-244) and read_assign (:776-836).  One
-// workgroup of four wavefronts: all threads turn the log-likelihood table into
-// weight rows L[q][s] = exp(ll - max_s ll) (fp32, in LDS when they fit, else in
-// HBM/L2), then run the chain (urn_chain_q).  NB = ceil(S / 16): every lane of a
-// quad owns 4 * NB consecutive strains.
-__host__ __device__ inline int chain_w_stride(int S) {
-    const int s4 = (S + 1 + 3) & ~3;                          // S weights + the read symbol
-    return (s4 & 4) ? s4 : s4 + 4;                            // 4 * odd
-}
+// workgroup: the fp32 weight rows L[q][s] = exp(ll - max_s ll) built by
+// k_level_table move into LDS when they fit (else they are read from HBM/L2),
+// then four or eight wavefronts run the chain (urn_chain_q).  NB = ceil(S / 16):
+// every lane of a quad owns 4 * NB consecutive strains.
 constexpr int CHAINW_ROWS_BYTES = LDS_BIG - UWIN * 4;
 constexpr int CHAIN_THREADS = 512;   // eight wavefronts build the weight rows
 // wavefronts that run the chain = window of 16 * NW draws: all eight while a lane's share of the strains is
@@ -816,24 +819,13 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain_w(JobDev job, const Lev
         s_a0f[tid] = tid < S ? (float)P->a0[tid] : 0.0f;
     }
     if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_pass = 0; R->chain_cycles = 0; R->chain_wall = 0; }
-    for (int q = tid; q < Q; q += nt) {
-        double m = -INFINITY;
-        for (int s = 0; s < S; s++) m = fmax(m, job.tabA[(long)s * job.qcap + q]);
-        const bool flag = !(m >= -600.0);                 // underflow range of the reference's exp(); also NaN / -inf
-        job.qflag[q] = flag ? 1 : 0;
-        job.qmax[q] = m;
-        float* Lf = ROWS_LDS ? (s_rows + (long)q * stride) : (job.tabLf + (long)q * stride);
-        for (int s = 0; s < S; s++) {
-            const double v = exp(job.tabA[(long)s * job.qcap + q] - m);
-            Lf[s] = flag ? __int_as_float(0x7fc00000) : (float)v;   // a NaN row sends the draw to the literal tier
-        }
-        // the read symbol rides behind the weights (a tiny denormal under a zero count: no effect on the sums)
-        const int c0 = job.qcode[q];
-        Lf[S] = __int_as_float(c0 < KMAX ? c0 : KMAX);
-        for (int s = S + 1; s < stride; s++) Lf[s] = 0.0f;
+    if (ROWS_LDS) {
+        // the weight rows (built by k_level_table) move into LDS
+        const int n4 = (Q * stride + 16) / 4;                 // stride is a multiple of 4
+        const f4v* src = reinterpret_cast<const f4v*>(job.tabLf);
+        f4v* dst = reinterpret_cast<f4v*>(s_rows);
+        for (int i = tid; i < n4; i += nt) dst[i] = src[i];
     }
-    // lanes read whole 16-strain blocks: keep what follows the last row finite
-    for (int i = tid; i < 16; i += nt) { float* Lf = ROWS_LDS ? (s_rows + (long)Q * stride) : (job.tabLf + (long)Q * stride); Lf[i] = 0.0f; }
     __syncthreads();
     constexpr int NW = chain_nw(NB);
     if (tid >= 64 * NW) return;                            // a finished wavefront no longer counts at the barriers below
@@ -1197,14 +1189,13 @@ void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, Level
         g = g > 64 ? 64 : g;
         hipLaunchKernelGGL(k_level_slots, dim3(g), dim3(256), 0, st, job, P, do_update);
     } else {
-        if (table) done |= LV_TABLE_ELSEWHERE;
         hipLaunchKernelGGL(k_level, dim3(1), dim3(512), LEVEL_LDS, st, job, P, R, do_update, done);
     }
     if (table) {
-        const long items = (long)S * H.Q;
-        int g = (int)((items + 511) / 512);
-        g = g < 1 ? 1 : (g > 128 ? 128 : g);
-        hipLaunchKernelGGL(k_level_table, dim3(g), dim3(256), 0, st, job, P);
+        int G = 1;
+        while (G < 16 && G * 8 < S) G <<= 1;                  // <= 8 strains per lane
+        const long threads = (long)H.Q * G;
+        hipLaunchKernelGGL(k_level_table, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, job, P, G);
     }
 }
 // S, Q of the level decide the chain variant and whether the fp32 rows fit in LDS.
