@@ -149,13 +149,14 @@ struct Ctx {
     std::vector<std::unique_ptr<Worker>> workers;
     double* dU = nullptr;             // uniform stream on the device
     float* dUf = nullptr;             // fp32 copy
+    bool blocking_sync = false;       // workers sleep in the per-level wait instead of spinning
 };
 
 struct Worker {
     Ctx* ctx;
     std::thread th;
     hipStream_t st = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
     LevelParams* Ph = nullptr;        // pinned staging
     LevelParams* Pd = nullptr;
     LevelResult* Rh = nullptr;        // host-mapped, written by the kernel
@@ -180,6 +181,7 @@ void Worker::init() {
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&ev0));
     HIPCHK(hipEventCreate(&ev1));
+    HIPCHK(hipEventCreateWithFlags(&ev_sync, hipEventBlockingSync | hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&Ph, sizeof(LevelParams), hipHostMallocDefault));
     HIPCHK(hipMalloc((void**)&Pd, sizeof(LevelParams)));
     HIPCHK(hipHostMalloc((void**)&Rh, sizeof(LevelResult), hipHostMallocMapped));
@@ -486,7 +488,13 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             launch_chain(st, jd, Pd, Rd, S, Q);
             if (timed) HIPCHK(hipEventRecord(ev1, st));
         }
-        HIPCHK(hipStreamSynchronize(st));
+        if (ctx->blocking_sync) {
+            // more regions in flight than host cores can spin for: sleep until the level is done
+            HIPCHK(hipEventRecord(ev_sync, st));
+            HIPCHK(hipEventSynchronize(ev_sync));
+        } else {
+            HIPCHK(hipStreamSynchronize(st));
+        }
         level_launches++;
         if (chain) {
             sampler_launches++; sampler_copies += Q;
@@ -817,6 +825,11 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
     }
     if (stream_count < 1) stream_count = 1;
     if (stream_count > 64) stream_count = 64;
+    {
+        const unsigned cores = std::thread::hardware_concurrency();
+        const char* e = getenv("SC_BLOCKING_SYNC");
+        ctx->blocking_sync = e ? (atoi(e) != 0) : (cores > 0 && (unsigned)stream_count + 1 > cores);
+    }
     for (int i = 0; i < stream_count; i++) {
         auto w = std::make_unique<Worker>();
         w->ctx = ctx;
@@ -840,6 +853,7 @@ void sc_ctx_destroy(sc_ctx* h) {
         if (w->Rh) (void)hipHostFree(w->Rh);
         if (w->ev0) (void)hipEventDestroy(w->ev0);
         if (w->ev1) (void)hipEventDestroy(w->ev1);
+        if (w->ev_sync) (void)hipEventDestroy(w->ev_sync);
         if (w->st) (void)hipStreamDestroy(w->st);
     }
     ctx->workers.clear();
@@ -1008,7 +1022,7 @@ int sc_msa_align(sc_ctx* h, const char* seq_text, const int* seq_off, int n, cha
         if (!rows_out || (long)n * (ncol + 1) > cap) rc = SC_ERR_CAPACITY;
         else for (int i = 0; i < n; i++) { std::memcpy(rows_out + (long)i * (ncol + 1), rows[i].data(), (size_t)ncol); rows_out[(long)i * (ncol + 1) + ncol] = 0; }
         (void)hipHostFree(w.Ph); (void)hipFree(w.Pd); (void)hipHostFree(w.Rh);
-        (void)hipEventDestroy(w.ev0); (void)hipEventDestroy(w.ev1); (void)hipStreamDestroy(w.st);
+        (void)hipEventDestroy(w.ev0); (void)hipEventDestroy(w.ev1); (void)hipEventDestroy(w.ev_sync); (void)hipStreamDestroy(w.st);
         return rc;
     } catch (const ScError& ex) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->last_error = ex.what(); return ex.code; }
     catch (const std::exception& ex) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->last_error = ex.what(); return SC_ERR_HIP; }
