@@ -31,7 +31,7 @@ def counter_avgs(path, counter):
             if row.get("Counter_Name") != counter:
                 continue
             name = row["Kernel_Name"]
-            key = "k_chain_w" if "k_chain_w" in name else ("k_level" if "k_level" in name else None)
+            key = "k_chain_w" if "k_chain_w" in name else ("k_level" if "sc::k_level(" in name else None)
             if key is None:
                 continue
             n, tot = per.get(key, (0, 0.0))
