@@ -54,6 +54,7 @@ typedef struct sc_params {
     int graph_only;        /* -G: build + dump the graph, no clustering */
     int want_trace;        /* keep the per-level strain/abundance trace */
     int want_timing;       /* time every sampler launch with HIP events on the region's stream (sc_stats) */
+    int want_graph;        /* keep the -G text (sc_roi_graph_dump) and the threading tables of a full run too */
 } sc_params;
 
 typedef struct sc_stats {

@@ -17,7 +17,7 @@ ERRORS = {-1: "SC_ERR_NO_DEVICE", -2: "SC_ERR_HIP", -3: "SC_ERR_ARG", -4: "SC_ER
 class ScParams(C.Structure):
     _fields_ = [("error_rate", C.c_float), ("tau", C.c_float), ("diff_rate", C.c_float),
                 ("sweeps_cap", C.c_int), ("draw_budget", C.c_int), ("max_candidates", C.c_int),
-                ("graph_only", C.c_int), ("want_trace", C.c_int), ("want_timing", C.c_int)]
+                ("graph_only", C.c_int), ("want_trace", C.c_int), ("want_timing", C.c_int), ("want_graph", C.c_int)]
 
 
 class ScStats(C.Structure):
@@ -68,8 +68,8 @@ EXPORTS = ["sc_ctx_create", "sc_ctx_destroy", "sc_last_error", "sc_roi_submit", 
            "sc_roi_thread_tables"]
 
 
-def default_params(error_rate=0.01, tau=0.02, diff_rate=0.01, graph_only=False, want_trace=False, want_timing=False):
-    return ScParams(error_rate, tau, diff_rate, 5000, 40000, 80, int(graph_only), int(want_trace), int(want_timing))
+def default_params(error_rate=0.01, tau=0.02, diff_rate=0.01, graph_only=False, want_trace=False, want_timing=False, want_graph=False):
+    return ScParams(error_rate, tau, diff_rate, 5000, 40000, 80, int(graph_only), int(want_trace), int(want_timing), int(want_graph))
 
 
 def _pack(strings):

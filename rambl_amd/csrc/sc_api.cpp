@@ -738,11 +738,13 @@ void Worker::process(Job& job) {
     ThreadFn thr = [this, &job](const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cg,
                           ThreadTables& T) {
         thread_device(G, R, cg, T);
-        job.thr_count = T.count; job.thr_first = T.minrid; job.thr_pool = T.pool; job.thr_sym.assign(T.sym.begin(), T.sym.end());
+        if (job.params.graph_only || job.params.want_graph) {      // kept for sc_roi_thread_tables
+            job.thr_count = T.count; job.thr_first = T.minrid; job.thr_pool = T.pool; job.thr_sym.assign(T.sym.begin(), T.sym.end());
+        }
     };
     PoGraph g(job.ref, job.reads, msa, thr);
     job.stats.msa_calls = g.msa_calls;
-    job.graph_dump = g.dump();
+    if (job.params.graph_only || job.params.want_graph) job.graph_dump = g.dump();      // -G text, PartialOrderGraph.cpp:318-337
     FlatGraph f;
     flatten(g, (int)job.reads.size(), f);
     job.stats.n_nodes = f.n_nodes; job.stats.n_levels = f.n_levels; job.stats.n_unique_reads = (int)job.reads.size();

@@ -805,6 +805,15 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
     f.node_label_str.resize(f.n_nodes); f.node_is_end.assign(f.n_nodes, 0);
     f.out_ptr.assign(f.n_nodes + 1, 0);
     f.pool_ptr.assign(f.n_nodes + 1, 0);
+    size_t n_pool = 0, n_lab = 0, n_out = 0;
+    for (int a = 0; a < f.n_nodes; a++) {
+        const GNode& x = g.nodes[alive[a]];
+        n_pool += x.pool.size(); n_out += x.out.size(); n_lab += x.lab.size();
+        for (const auto& e : x.pool) n_lab += e.lab.size();
+    }
+    f.pool_rid.reserve(n_pool); f.pool_cn.reserve(n_pool); f.out_node.reserve(n_out); f.labels.reserve(n_lab);
+    f.ent_rid.reserve(n_pool); f.ent_cn.reserve(n_pool); f.ent_node.reserve(n_pool); f.ent_lab_off.reserve(n_pool);
+    f.ent_lab_len.reserve(n_pool); f.ent_first.reserve(n_pool);
     for (int a = 0; a < f.n_nodes; a++) {
         const GNode& x = g.nodes[alive[a]];
         f.node_label_str[a] = x.lab;

@@ -81,7 +81,7 @@ def test_edge_support_kernel(seed, tmp_path):
     args = T.make_case(seed, str(tmp_path))
     pa = cli.parse_cmd_line(args)
     regs = cli.load_regions(pa)
-    params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate))
+    params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate), want_graph=True)
     with capi.Context(0, 1) as ctx:
         for window, reads in regs:
             if len(reads) == 0:
