@@ -133,6 +133,8 @@ struct HStrain {                      // host bookkeeping of one candidate (Stra
     int tail;                         // path arena index
     int node;                         // last node of the path
     uint64_t hash; int seqlen;        // rolling hash / length of strain_seq()
+    double lpc[KK];                   // cached log sub(a,b) - log comp(a); rows in `dirty` are stale
+    unsigned dirty;
 };
 struct PathRec { int node, parent; };
 
@@ -444,6 +446,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         for (int i = 0; i < KK; i++) s.sub[i] = 0;
         for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) s.sub[i * KMAX + j] = (i == j) ? 100 * (1 - e) : 100 * e;
         recount(s);
+        s.dirty = 0xFFu;
         s.abundance = 0; s.slot = free_slots.back(); free_slots.pop_back();
         s.tail = -1; s.node = -1; s.hash = 1469598103934665603ull; s.seqlen = 0;
         level_strains.push_back(s);
@@ -472,11 +475,15 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             P.lab_len[s] = sv[s].node >= 0 ? f.node_lab_len[sv[s].node] : 0;
             P.a0[s] = sv[s].abundance;
             P.logpri[s] = std::log(sv[s].abundance / za);
-            double* lp = P.lpt + (size_t)s * KK;
+            // log table of the strain: only the rows its counts changed in since the last level are recomputed
+            HStrain& hs = const_cast<HStrain&>(sv[s]);
             for (int a = 0; a < KMAX; a++) {
-                const double lc = (a < K) ? std::log(a < 6 ? sv[s].comp[a] : 0.0) : 0.0;   // log comp_count[a], Strain.cpp:132-135
-                for (int b = 0; b < KMAX; b++) lp[a * KMAX + b] = (a < K && b < K) ? std::log(sv[s].sub[a * KMAX + b]) - lc : 0.0;
+                if (!(hs.dirty & (1u << a))) continue;
+                const double lc = (a < K) ? std::log(a < 6 ? hs.comp[a] : 0.0) : 0.0;      // log comp_count[a], Strain.cpp:132-135
+                for (int b = 0; b < KMAX; b++) hs.lpc[a * KMAX + b] = (a < K && b < K) ? std::log(hs.sub[a * KMAX + b]) - lc : 0.0;
             }
+            hs.dirty = 0;
+            std::memcpy(P.lpt + (size_t)s * KK, hs.lpc, sizeof(double) * KK);
         }
         const size_t bytes = offsetof(LevelParams, lpt) + sizeof(double) * (size_t)S * KK;
         HIPCHK(hipMemcpyAsync(Pd, Ph, bytes, hipMemcpyHostToDevice, st));
@@ -594,8 +601,10 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                     st_.abundance += a[s];                                   // update_model, Strain.cpp:106-125
                     if (f.node_lab_len[st_.node] == 1) {
                         const int la = f.labels[f.node_lab_off[st_.node]];
-                        if (la < KMAX)
+                        if (la < KMAX) {
                             for (int b = 0; b < K; b++) if (cnt[s][b] > 0) st_.sub[la * KMAX + b] += cnt[s][b] / n;
+                            st_.dirty |= 1u << la;
+                        }
                     }
                     recount(st_);
                 }
@@ -619,7 +628,11 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                     HStrain& st_ = level_strains[s];
                     st_.abundance += Rh->abund[s];
                     for (int a = 0; a < K; a++)
-                        for (int b = 0; b < K; b++) st_.sub[a * KMAX + b] += Rh->subst[s * KK + a * KMAX + b];
+                        for (int b = 0; b < K; b++) {
+                            const double d = Rh->subst[s * KK + a * KMAX + b];
+                            st_.sub[a * KMAX + b] += d;
+                            if (d != 0.0) st_.dirty |= 1u << a;
+                        }
                     recount(st_);
                 }
             }
