@@ -307,8 +307,7 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
     int sym = 0;                                           // read symbol of this lane's draw (kept behind the row)
     auto issue_loads = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int g = 0; g < NQ; g++)                         // odd groups come from the HBM/L2 copy: two memory pipes share the rows
-            L[g] = (ROWS_LDS && (g & 1) == 0) ? *(const f4v*)(rows_lds + ro + cbase + 4 * g) : *(const SC_GLOBAL f4v*)(rows_g + ro + cbase + 4 * g);
+        for (int g = 0; g < NQ; g++) L[g] = ld4(ro + cbase + 4 * g);
         llast = ld1(ro + Sm1);
         sym = __float_as_int(ld1(ro + S));
         uf = s_uwin[upos];
