@@ -255,3 +255,31 @@ def test_msa_kernel_deep_and_long(oracle_bin):
         assert ctx.msa_align(seqs) == T.oracle_msa(seqs)
         with pytest.raises(capi.StrainCallError):
             ctx.msa_align(["A" * 10, "C" * 64])       # second sequence longer than 63: reported, not guessed
+
+
+@pytest.mark.parametrize("seed", [3, 16, 31])
+def test_reference_with_ambiguity_codes(seed, tmp_path, oracle_bin):
+    """N in the gene (16S references carry ambiguity codes): a seventh symbol in the node labels, and
+    the 'N in the strain label matches anything' rule of NonparametricClustering.cpp:358,372,384."""
+    import random
+    d = str(tmp_path)
+    args = T.make_case(seed, d)
+    fa = args[-2]
+    lines = open(fa).read().split("\n")
+    idx = [i for i, l in enumerate(lines) if l and not l.startswith(">")]
+    seq = list("".join(lines[i] for i in idx))
+    rng = random.Random(seed)
+    for _ in range(6):
+        seq[rng.randrange(len(seq))] = "N"
+    seq = "".join(seq)
+    k = 0
+    for i in idx:
+        n = len(lines[i])
+        lines[i] = seq[k:k + n]
+        k += n
+    open(fa, "w").write("\n".join(lines))
+    exp_fa, exp_tr = T.run_oracle(args, d, trace=True)
+    tf = os.path.join(d, "trace.txt")
+    got = T.run_product(args, trace_file=tf)
+    assert got == exp_fa
+    T.compare_traces(open(tf).read(), exp_tr)
