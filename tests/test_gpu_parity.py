@@ -56,6 +56,24 @@ def test_config2_full_size_matches_reference_fasta(tmp_path):
     assert got.count(">") >= 3
 
 
+def test_config4_deep_many_candidates_matches_reference_fasta(tmp_path):
+    """BASELINE.json configs[3] scaled to 100 000 reads (50 strains, depth 10 000 thinned by -D 800): tens
+    of candidate strains per level, so the wide variants of the sampler run.  The consensus FASTA must
+    equal the reference's own output (tests/golden/config4_deep, produced by oracle/_ref in the build
+    container)."""
+    import hashlib
+    import json
+    from rambl_amd import synth
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config4_deep")
+    meta = json.load(open(os.path.join(gold, "meta.json")))
+    gene = synth.make_gene(4, glen=1500, n_strains=50, n_reads=100000, name="deep4")
+    fa, sam = synth.write_dataset(str(tmp_path), [gene])
+    assert hashlib.sha256(open(fa, "rb").read()).hexdigest() == meta["fasta_sha256"]
+    assert hashlib.sha256(open(sam, "rb").read()).hexdigest() == meta["sam_sha256"]
+    got = T.run_product(meta["argv"] + [fa, sam])
+    assert got == open(os.path.join(gold, "expected.fa")).read()
+
+
 def _golden_cases():
     import json
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
