@@ -65,6 +65,8 @@ def test_config4_deep_many_candidates_matches_reference_fasta(tmp_path):
     import json
     from rambl_amd import synth
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config4_deep")
+    if not os.path.exists(os.path.join(gold, "meta.json")):
+        pytest.skip("fixture not generated (tests/golden/make_golden_large.py config4_deep)")
     meta = json.load(open(os.path.join(gold, "meta.json")))
     gene = synth.make_gene(4, glen=1500, n_strains=50, n_reads=100000, name="deep4")
     fa, sam = synth.write_dataset(str(tmp_path), [gene])
