@@ -85,10 +85,11 @@ def prepare_region(roi, fasta, bam, opts=None, shared=None):
 
 
 def run_regions(ctx, prepared, streams=1, params=None):
-    """prepared: list of (pa, [(window, reads)]).  Submits every window, `streams`
-    in flight, returns the FASTA text of each entry of `prepared`."""
+    """prepared: iterable of (pa, [(window, reads)]) -- a generator is consumed lazily, so the host
+    ingest of the next region overlaps the regions in flight.  Submits every window, `streams` in
+    flight, returns the FASTA text of each entry of `prepared` (in order) and the per-window stats."""
     from . import capi
-    texts = [[] for _ in prepared]
+    texts = []
     pending = []
     stats = []
 
@@ -100,6 +101,7 @@ def run_regions(ctx, prepared, streams=1, params=None):
             stats.append(res.stats)
 
     for idx, (pa, regs) in enumerate(prepared):
+        texts.append([])
         p_ = params or capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate))
         for wi, (window, reads) in enumerate(regs):
             if len(reads) == 0:
@@ -169,7 +171,7 @@ def strain_call(fasta, bam, out_dir=None, prefix="rambl", opts=None, device=0, s
     if streams > 4:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(streams, 24)))   # one hardware queue per region in flight
     shared = (samio.Fasta(fasta), fai, samio.Alignments(bam))
-    prepared = [prepare_region(rois[i], fasta, bam, opts, shared) for i in mine]
+    prepared = (prepare_region(rois[i], fasta, bam, opts, shared) for i in mine)     # ingest overlaps the regions in flight
     with capi.Context(device, streams) as ctx:
         texts, _ = run_regions(ctx, prepared, streams)
     if out_dir is not None:
