@@ -125,10 +125,11 @@ struct Job {
     std::string err;
 };
 
+typedef long double ld;               // the reference keeps abundances and counts in DoubleL = long double (x87 80-bit)
 struct HStrain {                      // host bookkeeping of one candidate (Strain, PartialOrderGraph.hpp:362-402)
-    double sub[KK];                   // sub_count over the symbol table
-    double comp[6]; double Z;
-    double abundance;
+    ld sub[KK];                       // sub_count over the symbol table
+    ld comp[6]; ld Z;
+    ld abundance;
     int slot;                         // row of the device read_loglik matrix
     int tail;                         // path arena index
     int node;                         // last node of the path
@@ -321,7 +322,7 @@ static void fmt_g17(std::string& out, double v) {
 void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     const int n_reads = (int)job.reads.size();
     const sc_params& pa = job.params;
-    const double e = (double)pa.error_rate, tau = (double)pa.tau, diff = (double)pa.diff_rate;
+    const ld e = (ld)pa.error_rate, tau = (ld)pa.tau, diff = (ld)pa.diff_rate;     // float widened, StrainCall.cpp:58-154
     const int K = f.K;
 
     // ---- pseudo level holding every read once, for read_assign (NonparametricClustering.cpp:776-836)
@@ -415,7 +416,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     auto trace_dump = [&](const char* when, int level, const std::vector<HStrain>& sv) {
         if (!want_trace || sv.empty()) return;
         tr += "------------------------------\n"; tr += when; tr += "\nlevel: "; tr += std::to_string(level); tr += "\n";
-        for (const auto& s : sv) { tr += strain_seq(s); tr += "\t"; fmt_g17(tr, s.abundance); tr += "\n"; }
+        for (const auto& s : sv) { tr += strain_seq(s); tr += "\t"; fmt_g17(tr, (double)s.abundance); tr += "\n"; }
     };
     auto sort_strains = [&](std::vector<HStrain>& sv) {                  // std::sort, abundance descending
         std::vector<int> perm(sv.size());
@@ -438,7 +439,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             else if (x == y) iden += 1;
             len += 1;
         }
-        return (iden + 0.0) / len;
+        return (ld)((iden + 0.0) / len);
     };
 
     {   // level_strains.push_back(Strain(100,e)), NonparametricClustering.cpp:281; Strain.cpp:41-71
@@ -467,20 +468,20 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         P.n_copy = (int)pending_copies.size();
         for (int c = 0; c < P.n_copy; c++) { P.copy_src[c] = pending_copies[c].first; P.copy_dst[c] = pending_copies[c].second; }
         pending_copies.clear();
-        double za = 0;
+        ld za = 0;
         for (int s = 0; s < S; s++) za += sv[s].abundance;                 // normalize(), :10-15
         for (int s = 0; s < S; s++) {
             P.slot[s] = sv[s].slot;
             P.lab_off[s] = sv[s].node >= 0 ? f.node_lab_off[sv[s].node] : 0;
             P.lab_len[s] = sv[s].node >= 0 ? f.node_lab_len[sv[s].node] : 0;
-            P.a0[s] = sv[s].abundance;
-            P.logpri[s] = std::log(sv[s].abundance / za);
+            P.a0[s] = (double)sv[s].abundance;
+            P.logpri[s] = (double)logl(sv[s].abundance / za);
             // log table of the strain: only the rows its counts changed in since the last level are recomputed
             HStrain& hs = const_cast<HStrain&>(sv[s]);
             for (int a = 0; a < KMAX; a++) {
                 if (!(hs.dirty & (1u << a))) continue;
-                const double lc = (a < K) ? std::log(a < 6 ? hs.comp[a] : 0.0) : 0.0;      // log comp_count[a], Strain.cpp:132-135
-                for (int b = 0; b < KMAX; b++) hs.lpc[a * KMAX + b] = (a < K && b < K) ? std::log(hs.sub[a * KMAX + b]) - lc : 0.0;
+                const ld lc = (a < K) ? logl(a < 6 ? hs.comp[a] : (ld)0) : (ld)0;          // log comp_count[a], Strain.cpp:132-135
+                for (int b = 0; b < KMAX; b++) hs.lpc[a * KMAX + b] = (a < K && b < K) ? (double)(logl(hs.sub[a * KMAX + b]) - lc) : 0.0;
             }
             hs.dirty = 0;
             std::memcpy(P.lpt + (size_t)s * KK, hs.lpc, sizeof(double) * KK);
@@ -572,10 +573,10 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                     last[s] = s;
                     for (int t = S - 1; t > s; t--) if (hs[t] == hs[s] && ln[t] == ln[s]) { last[s] = t; break; }
                 }
-                std::vector<double> prior(S), post(S), a(S);
+                std::vector<ld> prior(S), post(S), a(S);
                 for (int s = 0; s < S; s++) prior[s] = level_strains[last[s]].abundance;
                 run_level(MODE_SAMPLE, e0, e1, Q, n, true, level_strains, has_dups, any_multi);
-                std::vector<std::vector<double>> cnt(S, std::vector<double>(KMAX, 0.0));
+                std::vector<std::vector<ld>> cnt(S, std::vector<ld>(KMAX, 0));
                 if (S == 1 || n <= 0) {
                     // a single weight consumes no random numbers (libstdc++ discrete_distribution)
                     a[0] = level_strains[0].abundance;
@@ -584,15 +585,15 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                         const long tot = (long)n * Q;
                         for (long t = 0; t < tot; t++) a[0] += 1;
                         for (int x = e0; x < e1; x++)
-                            if (f.ent_lab_len[x] == 1) cnt[0][f.labels[f.ent_lab_off[x]]] += (double)n * f.ent_cn[x];
+                            if (f.ent_lab_len[x] == 1) cnt[0][f.labels[f.ent_lab_off[x]]] += (ld)n * f.ent_cn[x];
                     }
                 } else {
                     for (int s = 0; s < S; s++) {
-                        a[s] = Rh->abund[s];
-                        for (int b = 0; b < KMAX; b++) cnt[s][b] = (double)Rh->cnt[s * KMAX + b];
+                        a[s] = level_strains[s].abundance + (ld)Rh->kdraw[s];      // a[c] += 1 per draw, :195
+                        for (int b = 0; b < KMAX; b++) cnt[s][b] = (ld)Rh->cnt[s * KMAX + b];
                     }
                 }
-                double z = 0;
+                ld z = 0;
                 for (int s = 0; s < S; s++) z += a[s];
                 for (int s = 0; s < S; s++) a[s] /= z;
                 for (int s = 0; s < S; s++) a[s] *= Q;
@@ -609,14 +610,14 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                     recount(st_);
                 }
                 for (int s = 0; s < S; s++) post[s] = level_strains[last[s]].abundance;
-                double A_delta_max = 0;
-                for (int s = 0; s < S; s++) { double d = post[s] - prior[s]; if (A_delta_max < d) A_delta_max = d; }
-                double Z = 0;
+                ld A_delta_max = 0;
+                for (int s = 0; s < S; s++) { ld d = post[s] - prior[s]; if (A_delta_max < d) A_delta_max = d; }
+                ld Z = 0;
                 for (int s = 0; s < S; s++) Z += a[s];
-                const double Zt = Z * tau;
+                const ld Zt = Z * tau;
                 std::vector<HStrain> kept;
                 for (int s = 0; s < S; s++) {
-                    const double d = post[s] - prior[s];
+                    const ld d = post[s] - prior[s];
                     if (a[s] < Zt || d < 0.01 * A_delta_max) free_slots.push_back(level_strains[s].slot);
                     else kept.push_back(level_strains[s]);
                 }
@@ -626,11 +627,11 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 run_level(MODE_HARD, e0, e1, Q, 0, true, level_strains, has_dups, any_multi);
                 for (int s = 0; s < S; s++) {
                     HStrain& st_ = level_strains[s];
-                    st_.abundance += Rh->abund[s];
+                    st_.abundance += (ld)Rh->abund[s];
                     for (int a = 0; a < K; a++)
                         for (int b = 0; b < K; b++) {
                             const double d = Rh->subst[s * KK + a * KMAX + b];
-                            st_.sub[a * KMAX + b] += d;
+                            st_.sub[a * KMAX + b] += (ld)d;
                             if (d != 0.0) st_.dirty |= 1u << a;
                         }
                     recount(st_);
@@ -641,21 +642,21 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
 
         // ---- candidate extension, :473-551
         branching = false;
-        struct Cand { int parent; int node; double abundance; };
+        struct Cand { int parent; int node; ld abundance; };
         std::vector<Cand> cands;
         for (int si = 0; si < (int)level_strains.size(); si++) {
             const HStrain& s = level_strains[si];
             const int v = s.node;
             const int ob = f.out_ptr[v], oe = f.out_ptr[v + 1];
-            double oz = 0, moc = 0;
-            for (int x = ob; x < oe; x++) { const double oc0 = f.out_support[x]; oz += oc0; if (moc < oc0) moc = oc0; }
+            ld oz = 0, moc = 0;
+            for (int x = ob; x < oe; x++) { const ld oc0 = f.out_support[x]; oz += oc0; if (moc < oc0) moc = oc0; }
             int dd = 0;
             for (int x = ob; x < oe; x++) {
                 const int o = f.out_node[x];
-                const double oc = f.out_support[x];
+                const ld oc = f.out_support[x];
                 if (!f.node_is_end[o] && oz > 0) {
                     if (oc <= 1. && oc < moc) { dd += 1; continue; }
-                    double ab;
+                    ld ab;
                     if (oc > 0) ab = s.abundance * oc / oz;
                     else ab = oz * std::min(0.01, (double)tau);
                     cands.push_back({si, o, ab});
@@ -666,10 +667,10 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             if (oe - ob > 1 + dd) branching = true;
         }
         if ((int)cands.size() > pa.max_candidates) {                          // :532-551, Qx :246-254
-            std::vector<double> ssa;
+            std::vector<ld> ssa;
             for (auto& c : cands) ssa.push_back(c.abundance);
-            std::sort(ssa.begin(), ssa.end(), [](double x, double y) { return x > y; });
-            const double Zt0 = (pa.max_candidates >= (int)ssa.size()) ? ssa.back() : ssa[pa.max_candidates];
+            std::sort(ssa.begin(), ssa.end(), [](ld x, ld y) { return x > y; });
+            const ld Zt0 = (pa.max_candidates >= (int)ssa.size()) ? ssa.back() : ssa[pa.max_candidates];
             std::vector<Cand> kept;
             for (auto& c : cands) if (!(c.abundance < Zt0)) kept.push_back(c);
             cands.swap(kept);
@@ -706,16 +707,16 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     if (S > 0) {
         const int Q = (int)total_copies;
         const int n = std::min(pa.sweeps_cap, pa.draw_budget / std::max(Q, 1));
-        std::vector<double> a(S);
+        std::vector<ld> a(S);
         if (S == 1 || n <= 0) {
             for (int s = 0; s < S; s++) a[s] = fs[s].abundance;
             if (n > 0) { const long tot = (long)n * Q; for (long t = 0; t < tot; t++) a[0] += 1; }
         } else {
             pending_copies.clear();
             run_level(MODE_SAMPLE, final_e0, final_e0 + n_reads, Q, n, false, fs, false, true);
-            for (int s = 0; s < S; s++) a[s] = Rh->abund[s];
+            for (int s = 0; s < S; s++) a[s] = fs[s].abundance + (ld)Rh->kdraw[s];
         }
-        double z = 0;
+        ld z = 0;
         for (int s = 0; s < S; s++) z += a[s];
         for (int s = 0; s < S; s++) fs[s].abundance = a[s] / z;
         sort_strains(fs);
@@ -728,7 +729,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 if (pl != "^" && pl != "$" && pl != "-" && pl != "=") q += pl;
             }
             job.seqs.push_back(q);
-            job.abund.push_back(s.abundance);
+            job.abund.push_back((double)s.abundance);
         }
     }
     if (level_log) fclose(level_log);

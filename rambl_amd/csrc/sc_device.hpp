@@ -71,6 +71,7 @@ struct LevelResult {
     double abund[MAXS];          // HARD: sum of responsibilities; SAMPLE: urn weights a[] after the sweeps
     double subst[MAXS * KK];     // HARD: responsibility-weighted substitution counts
     unsigned cnt[MAXS * KMAX];   // SAMPLE: draws per (strain, read symbol)
+    unsigned kdraw[MAXS];        // SAMPLE: draws per strain (abund = a0 + kdraw, exactly)
     unsigned long long n_draws;
     unsigned long long n_slow;   // draws that went through the fp64 scan tier
     unsigned long long n_pass;   // window passes of the sampler chain

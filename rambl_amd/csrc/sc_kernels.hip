@@ -429,7 +429,7 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
 #pragma unroll
         for (int i = 0; i < NPLC; i++) {
             const int s = lane * NPLC + i;
-            if (s < S) R->abund[s] = a0m[i] + (double)s_kf[s];
+            if (s < S) { R->abund[s] = a0m[i] + (double)s_kf[s]; R->kdraw[s] = s_kf[s]; }
         }
         if (lane == 0) {
             R->n_draws = (unsigned long long)total; R->n_exact = n_exact; R->n_slow = n_slow; R->n_pass = n_pass;
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain_w(JobDev job, const Lev
             const int code = job.qcode[t % Q];
             if (code < KMAX) atomicAdd(&s_cnt[code], 1u);
         }
-        if (tid == 0) { R->abund[0] = P->a0[0] + (double)total; R->n_draws = (unsigned long long)total; }
+        if (tid == 0) { R->abund[0] = P->a0[0] + (double)total; R->kdraw[0] = (unsigned)total; R->n_draws = (unsigned long long)total; }
     } else {
         urn_chain_q<NB, ROWS_LDS, NW>(job, P, R, s_slot, s_a, s_p, s_kf, s_a0f, s_cnt, s_x, s_uwin, s_rows, stride, tid);
     }
