@@ -7,7 +7,9 @@ REFERENCE itself (oracle/_ref/StrainCall_ref, build container only; minutes to t
                 -D 800 -- many candidate strains per level (the wide sampler variants)
 
 Only the inputs' digests, the argv and the reference's stdout are stored.
-usage: python tests/golden/make_golden_large.py config2_full|config4_deep
+  tie_case525   sc_testlib.big_case(525): equal-abundance candidates told apart below fp64 resolution
+
+usage: python tests/golden/make_golden_large.py config2_full|config4_deep|tie_case525
 """
 import hashlib
 import json
@@ -40,14 +42,18 @@ def dataset(name, outdir):
         gene = synth.make_gene(4, glen=1500, n_strains=50, n_reads=100000, name="deep4")
         fa, sam = synth.write_dataset(outdir, [gene])
         return fa, sam, "deep4:1-1500", "rambl_amd.synth.make_gene(4, glen=1500, n_strains=50, n_reads=100000, name='deep4') + write_dataset"
+    if name == "tie_case525":
+        args, _ = T.big_case(525, outdir)
+        return args[-2], args[-1], None, "tests/sc_testlib.big_case(525, outdir)", args[:-2]
     raise SystemExit("unknown case " + name)
 
 
 def main():
     name = sys.argv[1]
     with tempfile.TemporaryDirectory() as d:
-        fa, sam, roi, gen = dataset(name, d)
-        argv = ["-r", roi] + OPTS
+        ds = dataset(name, d)
+        fa, sam, roi, gen = ds[:4]
+        argv = ds[4] if len(ds) > 4 else ["-r", roi] + OPTS
         env = dict(os.environ)
         env["PATH"] = T.TOOLS + os.pathsep + env.get("PATH", "")
         env["TMPDIR"] = d

@@ -67,6 +67,22 @@ def make_case(seed, outdir):
     return args + [fa, sam]
 
 
+def big_case(seed, outdir):
+    """Larger regions than `scenario` makes: more strains, noisier reads -> many candidate strains
+    (tools/parity_sweep.py --big; tests/golden/tie_case525)."""
+    rng = random.Random(seed * 7919 + 3)
+    kw = dict(glen=rng.randint(500, 900), n_strains=rng.randint(3, 7), n_reads=rng.randint(1200, 3500),
+              rlen=rng.choice([100, 150]), err=rng.choice([0.005, 0.01, 0.02, 0.03]),
+              n_sub=rng.randint(6, 20), n_ins=rng.randint(0, 3), n_del=rng.randint(0, 3),
+              paired=rng.random() < 0.3, shared_ins_site=rng.random() < 0.3)
+    gene = synth.make_gene(seed, name="b%d" % seed, **kw)
+    fa, sam = synth.write_dataset(outdir, [gene])
+    D = rng.choice([200, 400, 800])
+    t = rng.choice([0.02, 0.01, 0.005])
+    return ["-r", "%s:1-%d" % (gene["name"], len(gene["ref"])), "-q", "0", "-D", str(D), "-I", "13", "-l", "70",
+            "-t", str(t), "-d", "0.02", "-w", "5000", fa, sam], kw
+
+
 def run_oracle(args, cwd, trace=False, graph=False, dump_reads=None, timeout=3000):
     env = dict(os.environ)
     env["PATH"] = TOOLS + os.pathsep + env.get("PATH", "")
