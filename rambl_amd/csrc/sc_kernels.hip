@@ -719,12 +719,21 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
         __syncthreads();
         for (int q = tid; q < Q; q += nt) {
             const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
-            double norm = 0;
+            // p_s = exp(x_s) / sum_s exp(x_s) (:186-192).  The reference forms it in long double, where
+            // exp(-800) is an ordinary number (a read laid against a long collapsed node it does not match
+            // reaches such log-likelihoods for every strain); in fp64 the same quotient needs the maximum
+            // taken out first.  A NaN x_s still makes every p NaN, as in the reference.
+            double m = -INFINITY;
             for (int s = 0; s < S; s++) {
                 const double* row = job.ll + (long)s_slot[s] * stride;
                 double x = s_logpri[s] + row[rid];
                 if (uid >= 0) x += row[uid];
-                const double p = exp(x);
+                job.tabA[(long)s * job.qcap + q] = x;
+                m = fmax(m, x);
+            }
+            double norm = 0;
+            for (int s = 0; s < S; s++) {
+                const double p = exp(job.tabA[(long)s * job.qcap + q] - m);
                 job.tabA[(long)s * job.qcap + q] = p;
                 norm += p;
             }

@@ -9,7 +9,9 @@ import sc_testlib as T
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", list(range(0, 16)))
+# 312: log-likelihoods below -745 for every candidate at a soft-update level (fp64 exp underflow); 465: NaN
+# abundances in the reference itself
+@pytest.mark.parametrize("seed", list(range(0, 16)) + [312, 465])
 def test_region_parity(seed, tmp_path, oracle_bin):
     d = str(tmp_path)
     args = T.make_case(seed, d)
