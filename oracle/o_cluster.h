@@ -311,6 +311,10 @@ static void sort_strains(StrainVec *sv) {
 static void merge_strains(StrainVec *sv, ld diff) {
     sort_strains(sv);
     int n = sv->n;
+    /* No candidate left (every one was pruned): the reference copy-constructs `merged` from strains[0] of an
+     * EMPTY vector (:650) -- undefined behaviour that, in the shipped and the rebuilt binary alike, ends in an
+     * empty stdout and exit status 0.  The restatement keeps the empty set. */
+    if (n == 0) return;
     char **seqs = (char **)xmalloc(sizeof(char *) * (size_t)n);
     for (int i = 0; i < n; i++) seqs[i] = strain_seq(&sv->v[i]);
     IntVec merged; vec_init(merged);

@@ -532,7 +532,10 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 s.abundance = 1;
             } else if (f.node_is_end[u]) {
                 // read_reassign (only its sort has an effect, :672-702), merge_strains (:645-670)
-                if (level_strains.empty()) throw ScError(SC_ERR_INTERNAL, "every candidate strain was pruned");
+                // Every candidate pruned before the end of the gene: the reference runs into undefined behaviour here
+                // (merged(1, strains[0]) of an empty vector, :650) and in practice prints nothing and exits 0; so does
+                // this path (no contig for the region).
+                if (level_strains.empty()) { final_strains.clear(); continue; }
                 sort_strains(level_strains);
                 sort_strains(level_strains);
                 std::vector<std::string> seqs;
