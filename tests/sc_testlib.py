@@ -83,6 +83,27 @@ def big_case(seed, outdir):
             "-t", str(t), "-d", "0.02", "-w", "5000", fa, sam], kw
 
 
+def param_case(seed, outdir):
+    """Small regions with the command-line parameters varied (-e -t -d -l -I -D -w -o)."""
+    rng = random.Random(seed * 31337 + 11)
+    kw = dict(glen=rng.randint(240, 480), n_strains=rng.randint(1, 4), n_reads=rng.randint(60, 320),
+              rlen=rng.choice([100, 120, 150]), err=rng.choice([0.0, 0.005, 0.02]),
+              n_sub=rng.randint(2, 12), n_ins=rng.randint(0, 2), n_del=rng.randint(0, 2),
+              paired=rng.random() < 0.25, shared_ins_site=rng.random() < 0.25)
+    gene = synth.make_gene(seed, name="p%d" % seed, **kw)
+    fa, sam = synth.write_dataset(outdir, [gene])
+    glen = len(gene["ref"])
+    opts = ["-r", "%s:1-%d" % (gene["name"], glen), "-q", "0",
+            "-D", str(rng.choice([10, 50, 800])), "-I", str(rng.choice([3, 13])), "-l", str(rng.choice([40, 70, 100])),
+            "-t", rng.choice(["0.005", "0.02", "0.1"]), "-d", rng.choice(["0.005", "0.02", "0.05"]),
+            "-e", rng.choice(["0.001", "0.01", "0.05"])]
+    if rng.random() < 0.3:
+        opts += ["-w", str(rng.choice([150, 200, 300])), "-o", str(rng.choice([30, 50, 100]))]
+    else:
+        opts += ["-w", "5000"]
+    return opts + [fa, sam], kw
+
+
 def run_oracle(args, cwd, trace=False, graph=False, dump_reads=None, timeout=3000, check=True):
     env = dict(os.environ)
     env["PATH"] = TOOLS + os.pathsep + env.get("PATH", "")

@@ -2,7 +2,7 @@
 """Wide parity sweep on a GPU box: product (HIP path through the C-ABI) against the C oracle (test
 infrastructure) on many seeded scenarios, FASTA byte-for-byte and per-level abundance traces to 1e-9.
 The oracle runs of different scenarios proceed in parallel on the host cores; the product runs one
-region at a time.  Usage: python3 tools/parity_sweep.py FIRST_SEED N [--big] [--jobs J]"""
+region at a time.  Usage: python3 tools/parity_sweep.py FIRST_SEED N [--big | --params] [--jobs J]"""
 import concurrent.futures as cf
 import os
 import sys
@@ -20,6 +20,7 @@ big_case = T.big_case
 def main():
     first, n = int(sys.argv[1]), int(sys.argv[2])
     big = "--big" in sys.argv
+    params = "--params" in sys.argv
     jobs = int(sys.argv[sys.argv.index("--jobs") + 1]) if "--jobs" in sys.argv else 1
     bad = crashed = 0
     t0 = time.time()
@@ -28,6 +29,9 @@ def main():
         d = tempfile.mkdtemp(prefix="sweep%d_" % seed)
         if big:
             args, kw = big_case(seed, d)
+        elif params:
+            args, kw = T.param_case(seed, d)
+            kw = dict(kw, argv=args[:-2])
         else:
             args, kw = T.make_case(seed, d), T.scenario(seed)[0]
         return seed, d, args, kw
