@@ -217,7 +217,14 @@ int Worker::msa_device(const std::vector<std::string>& seqs, std::vector<std::st
     int out[2];
     HIPCHK(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (out[1] & 0xFF) throw ScError(SC_ERR_UNSUPPORTED, "MSA kernel capacity exceeded");
+    if (out[1] & 0xFF) {
+        size_t longest = 0;
+        for (auto& q : seqs) longest = std::max(longest, q.size());
+        throw ScError(SC_ERR_UNSUPPORTED, "MSA kernel capacity exceeded (" + std::string((out[1] & 1) ? "a sequence longer than 63; " : "") +
+                      std::string((out[1] & 2) ? "more than 1024 columns; " : "") + std::string((out[1] & 4) ? "column buffer; " : "") +
+                      std::string((out[1] & 8) ? "more than 65535 sequences; " : "") + std::to_string(n) + " sequences, longest " +
+                      std::to_string(longest) + ", columns so far " + std::to_string(out[0]) + ")");
+    }
     const int ncol = out[0], cur = out[1] >> 8;
     std::vector<char> cols((size_t)ncol * n);
     if (ncol > 0) HIPCHK(hipMemcpy(cols.data(), d.cols[cur], (size_t)ncol * n, hipMemcpyDeviceToHost));

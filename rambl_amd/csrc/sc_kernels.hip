@@ -886,17 +886,23 @@ __device__ __forceinline__ int dna_score_cls(int x, int y) {
 constexpr int MSA_CM = 1024;                       // widest alignment (columns) kept in LDS
 constexpr size_t MSA_LDS = 2 * MSA_CM * 10 * sizeof(unsigned short) + 2 * MSA_CM + (MSA_CM + 1) * 64 + 2 * (MSA_CM + 64) * sizeof(int);
 
+// WIDE: the alignment may grow past MSA_CM columns (hundreds of distinct insertion strings at one site:
+// the reference's scoring tends to open new columns); the same state then lives in HBM scratch sized for
+// the sum of the sequence lengths instead of LDS.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_msa(MsaDev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char m_raw[];
-    unsigned short* s_cnt = reinterpret_cast<unsigned short*>(m_raw);            // [2][MSA_CM][10] class counts per column
-    char* s_c0 = reinterpret_cast<char*>(s_cnt + 2 * MSA_CM * 10);                // [2][MSA_CM] row-0 character per column
-    unsigned char* s_mv = reinterpret_cast<unsigned char*>(s_c0 + 2 * MSA_CM);    // [(MSA_CM+1)][64] traceback moves
-    int* s_trace = reinterpret_cast<int*>(s_mv + (MSA_CM + 1) * 64);              // [2*(MSA_CM+64)]
+    const int CM = WIDE ? d.cmax : MSA_CM;                                        // capacity in columns
+    unsigned short* s_cnt = WIDE ? reinterpret_cast<unsigned short*>(d.counts)    // [2][CM][10] class counts per column
+                                 : reinterpret_cast<unsigned short*>(m_raw);
+    char* s_c0 = reinterpret_cast<char*>(s_cnt + 2 * (size_t)CM * 10);            // [2][CM] row-0 character per column
+    unsigned char* s_mv = WIDE ? d.moves : reinterpret_cast<unsigned char*>(s_c0 + 2 * CM);    // [(CM+1)][64] traceback moves
+    int* s_trace = WIDE ? d.trace : reinterpret_cast<int*>(s_mv + (CM + 1) * 64);              // [2*(CM+64)]
     __shared__ int s_ncol, s_newn, s_err;
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
     const int n = d.n;
     int cur = 0;
-    if (tid == 0) { s_ncol = d.seq_off[1] - d.seq_off[0]; s_err = (s_ncol > MSA_CM || n > 65535) ? 1 : 0; }
+    if (tid == 0) { s_ncol = d.seq_off[1] - d.seq_off[0]; s_err = (s_ncol > CM ? 2 : 0) | (n > 65535 ? 8 : 0); }
     __syncthreads();
     if (!s_err) {   // first sequence: one column per character
         const int l0 = s_ncol;
@@ -917,10 +923,14 @@ __global__ __launch_bounds__(256) void k_msa(MsaDev d) {
         const char* seq = d.seqs + d.seq_off[t];
         const int len = d.seq_off[t + 1] - d.seq_off[t];
         const int nn = len + 1;
-        if (nn > 64 || ncol + len > MSA_CM || ncol + len > d.cmax) { if (tid == 0) s_err = 1; __syncthreads(); break; }
+        if (nn > 64 || ncol + len > CM || ncol + len > d.cmax) {
+            if (tid == 0) s_err = (nn > 64 ? 1 : 0) | (ncol + len > CM ? 2 : 0) | (ncol + len > d.cmax ? 4 : 0);
+            __syncthreads();
+            break;
+        }
         const char* colc = d.cols[cur];
-        const unsigned short* cntc = s_cnt + cur * MSA_CM * 10;
-        const char* c0c = s_c0 + cur * MSA_CM;
+        const unsigned short* cntc = s_cnt + (size_t)cur * CM * 10;
+        const char* c0c = s_c0 + (size_t)cur * CM;
         // ---- forward, wave 0: lane j = DP column j, time step tau handles row i = tau - j
         if (tid < 64) {
             const int j = lane;
@@ -967,7 +977,7 @@ __global__ __launch_bounds__(256) void k_msa(MsaDev d) {
                         if (r1 >= r2 && r1 >= r3) { sc_new = r1; st_new = (c0 == '-') ? 1 : 0; mv = 0; }
                         else if (r2 >= r1 && r2 >= r3) { sc_new = r2; st_new = 1; mv = 1; }
                         else { sc_new = r3; st_new = (c0 == '-') ? 0 : 2; mv = 2; }
-                        s_mv[i * 64 + j] = mv;
+                        s_mv[(size_t)i * 64 + j] = mv;
                     }
                 }
                 // what lane j-1 held BEFORE this step is cell (i-1, j-1) for the next step
@@ -982,7 +992,7 @@ __global__ __launch_bounds__(256) void k_msa(MsaDev d) {
             int r1 = ncol - 1, r2 = len - 1;
             while (!(x == 0 && y == 0)) {
                 int mv;
-                if (x == 0) mv = 1; else if (y == 0) mv = 2; else mv = s_mv[x * 64 + y];
+                if (x == 0) mv = 1; else if (y == 0) mv = 2; else mv = s_mv[(size_t)x * 64 + y];
                 if (mv == 0) { s_trace[2 * cnt] = r1; s_trace[2 * cnt + 1] = r2; --r1; --r2; --x; --y; }
                 else if (mv == 1) { s_trace[2 * cnt] = -1; s_trace[2 * cnt + 1] = r2; --r2; --y; }
                 else { s_trace[2 * cnt] = r1; s_trace[2 * cnt + 1] = -1; --r1; --x; }
@@ -994,8 +1004,8 @@ __global__ __launch_bounds__(256) void k_msa(MsaDev d) {
         // ---- rebuild columns (reversed traceback order); counts follow incrementally
         const int newn = s_newn;
         char* coln = d.cols[cur ^ 1];
-        unsigned short* cntn = s_cnt + (cur ^ 1) * MSA_CM * 10;
-        char* c0n = s_c0 + (cur ^ 1) * MSA_CM;
+        unsigned short* cntn = s_cnt + (size_t)(cur ^ 1) * CM * 10;
+        char* c0n = s_c0 + (size_t)(cur ^ 1) * CM;
         for (long idx = tid; idx < (long)newn * (s + 1); idx += nt) {
             const int c = (int)(idx / (s + 1)), k = (int)(idx % (s + 1));
             const int src = s_trace[2 * (newn - 1 - c)], sj = s_trace[2 * (newn - 1 - c) + 1];
@@ -1162,7 +1172,7 @@ template <int NB, bool L> static int set_chain_w_attr() {
 }
 int init_kernels() {
     int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEVEL_LDS);
-    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msa), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSA_LDS);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msa<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSA_LDS);
     rc |= set_chain_w_attr<1, true>(); rc |= set_chain_w_attr<1, false>();
     rc |= set_chain_w_attr<2, true>(); rc |= set_chain_w_attr<2, false>();
     rc |= set_chain_w_attr<3, true>(); rc |= set_chain_w_attr<3, false>();
@@ -1219,7 +1229,10 @@ void launch_chain(hipStream_t st, const JobDev& job, const LevelParams* P, Level
     }
 #undef SC_CHAINW
 }
-void launch_msa(hipStream_t st, const MsaDev& d) { hipLaunchKernelGGL(k_msa, dim3(1), dim3(256), MSA_LDS, st, d); }
+void launch_msa(hipStream_t st, const MsaDev& d) {
+    if (d.cmax > MSA_CM) hipLaunchKernelGGL(k_msa<true>, dim3(1), dim3(256), 0, st, d);      // state in HBM scratch
+    else hipLaunchKernelGGL(k_msa<false>, dim3(1), dim3(256), MSA_LDS, st, d);
+}
 // a5 in four launches; `pool_sorted` receives the class pools in read order.
 void launch_thread(hipStream_t st, const ThreadDev& d, int* pool_sorted) {
     const int ncls = d.glen * 8;

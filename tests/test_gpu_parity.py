@@ -262,6 +262,19 @@ def test_thread_kernels_class_tables(seed, tmp_path):
             assert off == len(pool)
 
 
+def test_msa_kernel_wider_than_lds(oracle_bin):
+    """Hundreds of unrelated insertion strings at one site: the reference's scoring keeps opening columns,
+    the alignment outgrows the 1 024 columns kept in LDS and k_msa<true> (state in HBM) takes over."""
+    from rambl_amd import capi
+    rng = random.Random(23)
+    seqs = ["".join(rng.choice("ACGT") for _ in range(rng.randint(4, 11))) for _ in range(260)]
+    seqs.sort(key=len, reverse=True)
+    exp = T.oracle_msa(seqs)
+    assert len(exp[0]) > 1024, len(exp[0])
+    with capi.Context(0, 1) as ctx:
+        assert ctx.msa_align(seqs) == exp
+
+
 def test_msa_kernel_deep_and_long(oracle_bin):
     """k_msa with hundreds of rows (deep coverage at an indel hot spot) and with insertions up to
     the 63-base limit of the one-wavefront DP."""
