@@ -861,10 +861,8 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
                     f.ent_first.push_back(rid_stamp[e.rid] != level);
                     rid_stamp[e.rid] = level;
                     lrc += e.cn;
-                    // sb single-char, rb multi-char: the reference looks up sub_count[(c,"multi")],
-                    // a key the device symbol table cannot express
-                    if (x.lab.size() == 1 && e.lab.size() > 1 && f.unsupported.empty())
-                        f.unsupported = "single-character node label with multi-character read label";
+                    // (a single-character strain label against a multi-character read label is modelled on the
+                    // device: the reference looks up the never-set key sub_count[(c, "multi")] -> log 0, k_level)
                 }
             }
             for (int o : x.out) {

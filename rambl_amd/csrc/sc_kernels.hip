@@ -613,8 +613,15 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
             double val;
             if (ls == 1) {
                 int a = sb[0], b = rb[0];
-                if (a == codeN) a = b;
-                val = (lr == 1 && a < K && b < K) ? lp[a * KMAX + b] : __longlong_as_double(0x7ff8000000000000ll);
+                if (lr == 1) {
+                    if (a == codeN) a = b;
+                    val = (a < K && b < K) ? lp[a * KMAX + b] : __longlong_as_double(0x7ff8000000000000ll);
+                } else {
+                    // logprob(sb, "multi"): sub_count[(sb, rb)] is created as 0 (std::map operator[]), so the
+                    // result is log 0 - log comp(sb) = -inf for a symbol of the alphabet; for N (sb becomes rb)
+                    // or a symbol outside the alphabet comp is created as 0 too: -inf - -inf
+                    val = (a < 6 && a != codeN) ? -INFINITY : __longlong_as_double(0x7ff8000000000000ll);
+                }
             } else {
                 val = 0.0;
                 if (job.isnew[r]) {

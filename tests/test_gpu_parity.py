@@ -11,8 +11,9 @@ pytestmark = pytest.mark.gpu
 
 # 312: log-likelihoods below -745 for every candidate at a soft-update level (fp64 exp underflow); 465: NaN
 # abundances in the reference itself; 744: every candidate pruned before the end of the gene (the reference
-# prints nothing and exits 0)
-@pytest.mark.parametrize("seed", list(range(0, 16)) + [312, 465, 744])
+# prints nothing and exits 0); 7705: a single-character strain label against a two-character read label (the
+# reference's never-set count -> log 0)
+@pytest.mark.parametrize("seed", list(range(0, 16)) + [312, 465, 744, 7705])
 def test_region_parity(seed, tmp_path, oracle_bin):
     d = str(tmp_path)
     args = T.make_case(seed, d)
