@@ -27,6 +27,18 @@ def test_region_parity(seed, tmp_path, oracle_bin):
     T.compare_traces(open(tf).read(), exp_tr)  # per-level candidates identical, abundances to 1e-9
 
 
+@pytest.mark.parametrize("seed", list(range(0, 12)))
+def test_region_parity_with_varied_parameters(seed, tmp_path, oracle_bin):
+    """-e -t -d -l -I -D -w -o varied (sc_testlib.param_case)."""
+    d = str(tmp_path)
+    args, _ = T.param_case(seed, d)
+    exp_fa, exp_tr = T.run_oracle(args, d, trace=True)
+    tf = os.path.join(d, "trace.txt")
+    got_fa = T.run_product(args, trace_file=tf)
+    assert got_fa == exp_fa
+    T.compare_traces(open(tf).read(), exp_tr)
+
+
 def test_msa_kernel_random(oracle_bin):
     from rambl_amd import capi
     rng = random.Random(5)
