@@ -186,9 +186,10 @@ def main():
                     pa16 = cli.parse_cmd_line(stage5.straincall_argv("%s:1-%d" % (g16["name"], a.glen), fa16, sam16))
                     prep16.append((pa16, cli.load_regions(pa16)))
                 ctx16 = capi.Context(local, 16)
-                stage5.run_regions(ctx16, prep16, 16, params)
+                params16 = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate))   # no per-launch events
+                stage5.run_regions(ctx16, prep16, 16, params16)
                 t1 = time.time()
-                stage5.run_regions(ctx16, prep16, 16, params)
+                stage5.run_regions(ctx16, prep16, 16, params16)
                 dt16 = time.time() - t1
                 ctx16.close()
                 line["regions_in_flight"] = {"regions": 16, "reads": 16 * a.reads, "value": 16 * a.reads / dt16, "unit": "reads/s",
