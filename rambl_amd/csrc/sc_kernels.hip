@@ -1,16 +1,19 @@
 // HIP kernels of the StrainCall path for gfx950 (MI355X, CDNA4, wave64).
 //
-//   k_edge_support   number_of_reads_cover_nodes for every edge            (row a16)
-//   k_level          per-level read log-likelihood update (a13) followed by
-//                    the soft update (a15, hard_clustering) or the Polya-urn
-//                    sampler (a14, np_bayes_clustering; also a18, read_assign)
-//   k_msa            progressive sum-of-pairs MSA of insertion strings      (a7, a8)
+//   k_thread_*       threading of the reads along the backbone                 (row a5)
+//   k_msa            progressive sum-of-pairs MSA of insertion strings          (a7, a8)
+//   k_edge_support   number_of_reads_cover_nodes for every edge                (a16)
+//   k_level_*        per-level read log-likelihood update, draw slots and the
+//                    sampler's tables on a grid (a13); k_level: the order-
+//                    dependent rest and the soft update (a15, hard_clustering)
+//   k_chain_w        the Polya-urn sampler of one level (a14, np_bayes_clustering;
+//                    also a18, read_assign)
 //
-// These are integer / fp64 latency- and HBM-bound loops: no MFMA.  The sampler is
-// one dependent chain per region; one wavefront runs it with one candidate strain
-// per lane (two per lane above 64), a DPP prefix scan for the categorical draw and
-// a margin test that sends near-ties to a literal fp64 evaluation of the
-// reference's formula, so every draw equals the reference's draw.
+// These are integer / fp32 / fp64 loops bound by latency or HBM: no MFMA.  The
+// sampler is one dependent chain per region; four or eight wavefronts speculate
+// over a window of draws and prove every accepted decision equal to the
+// sequential one, near-ties go to an fp64 scan and then to a literal evaluation of
+// the reference's formula, so every draw equals the reference's draw.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -139,20 +142,6 @@ __device__ int exact_draw(const SlowArgs job, const int* s_slot, const volatile 
 }
 
 constexpr double DRAW_EPS64 = 1e-10;  // margin (relative to the total weight) of the fp64 scan tier
-
-template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
-__device__ __forceinline__ float dpp_f32(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, BOUND));
-}
-__device__ __forceinline__ float wave_scan_incl_f32(float v) {
-    v += dpp_f32<0x111, 0xF, 0xF, true>(v);
-    v += dpp_f32<0x112, 0xF, 0xF, true>(v);
-    v += dpp_f32<0x114, 0xF, 0xF, true>(v);
-    v += dpp_f32<0x118, 0xF, 0xF, true>(v);
-    v += dpp_f32<0x142, 0xA, 0xF, false>(v);
-    v += dpp_f32<0x143, 0xC, 0xF, false>(v);
-    return v;
-}
 
 // Tier 2 and 3 of one draw: fp64 weights and scan with a 1e-10 margin; if the
 // uniform is still within the margin of a boundary (or the slot is flagged for
