@@ -17,14 +17,22 @@ _LEAD_INT = re.compile(r"\s*([+-]?\d+)")
 
 def stoi(s):
     """std::stoi: leading integer, junk after it ignored; no digits -> error."""
+    if s.isdigit():                                # the usual field: plain decimal digits
+        return int(s)
     m = _LEAD_INT.match(s)
     if not m:
         raise ValueError("stoi: no conversion for %r" % (s,))
     return int(m.group(1))
 
 
+_CIGAR_OK = re.compile(r"(?:\d+[MIDNSHP=X])+\Z")
+_CIGAR_OP = re.compile(r"(\d+)([MIDNSHP=X])")
+
+
 def parse_cigar(cigar):
     """PartialOrderGraph.cpp:13-59: [(op, len)], '=' and 'X' become 'M'."""
+    if _CIGAR_OK.match(cigar):                     # well-formed: same result as the character loop below
+        return [("M" if op in "=X" else op, int(n)) for n, op in _CIGAR_OP.findall(cigar)]
     out = []
     num = ""
     for ch in cigar:

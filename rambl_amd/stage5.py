@@ -84,6 +84,28 @@ def prepare_region(roi, fasta, bam, opts=None, shared=None):
     return pa, out
 
 
+_POOL_SHARED = None
+
+
+def _pool_init(fasta, bam):
+    global _POOL_SHARED
+    _POOL_SHARED = (samio.Fasta(fasta), samio.read_fai(fasta + ".fai"), samio.Alignments(bam))
+
+
+def _pool_prepare(job):
+    roi, fasta, bam, opts = job
+    return prepare_region(roi, fasta, bam, opts, _POOL_SHARED)
+
+
+def ingest_pool(fasta, bam, workers):
+    """Host ingest (rows a1-a4) of different regions on several cores.  Created BEFORE anything initialises
+    the GPU in this process (plain fork, no exec; the children never touch it)."""
+    import multiprocessing
+    if workers <= 1:
+        return None
+    return multiprocessing.get_context("fork").Pool(workers, initializer=_pool_init, initargs=(fasta, bam))
+
+
 def run_regions(ctx, prepared, streams=1, params=None):
     """prepared: iterable of (pa, [(window, reads)]) -- a generator is consumed lazily, so the host
     ingest of the next region overlaps the regions in flight.  Submits every window, `streams` in
@@ -158,7 +180,7 @@ def gather_fasta(local_texts, local_ids, n_units, dist=None, device=None):
     return "".join(out)
 
 
-def strain_call(fasta, bam, out_dir=None, prefix="rambl", opts=None, device=0, streams=4, dist=None, torch_device=None):
+def strain_call(fasta, bam, out_dir=None, prefix="rambl", opts=None, device=0, streams=4, dist=None, torch_device=None, pool=None):
     """rambl.py `strain_call` for this rank's shard; rank 0 returns the concatenated
     FASTA (and writes <out_dir>/3_straincall_results/<roi>.fa + <prefix>.fa)."""
     from . import capi
@@ -170,8 +192,11 @@ def strain_call(fasta, bam, out_dir=None, prefix="rambl", opts=None, device=0, s
     mine = lpt_shards(costs, world)[rank]
     if streams > 4:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(streams, 24)))   # one hardware queue per region in flight
-    shared = (samio.Fasta(fasta), fai, samio.Alignments(bam))
-    prepared = (prepare_region(rois[i], fasta, bam, opts, shared) for i in mine)     # ingest overlaps the regions in flight
+    if pool is not None:
+        prepared = pool.imap(_pool_prepare, [(rois[i], fasta, bam, opts) for i in mine], chunksize=1)
+    else:
+        shared = (samio.Fasta(fasta), fai, samio.Alignments(bam))
+        prepared = (prepare_region(rois[i], fasta, bam, opts, shared) for i in mine)     # ingest overlaps the regions in flight
     with capi.Context(device, streams) as ctx:
         texts, _ = run_regions(ctx, prepared, streams)
     if out_dir is not None:
@@ -197,6 +222,7 @@ def main(argv=None):
     ap.add_argument("-o", "--out-dir", default=".")
     ap.add_argument("-p", "--prefix", default="rambl")
     ap.add_argument("-s", "--streams", type=int, default=8, help="regions in flight per GPU")
+    ap.add_argument("-j", "--ingest-workers", type=int, default=8, help="host processes reading the alignments")
     for k, v in RAMBL_DEFAULTS.items():
         ap.add_argument("--" + k.replace("_", "-"), default=v, type=type(v))
     a = ap.parse_args(argv)
@@ -206,6 +232,7 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.streams > 4:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(a.streams, 24)))
+    pool = ingest_pool(a.fasta, a.alignments, a.ingest_workers)      # before anything touches the GPU
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -214,7 +241,9 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     full = strain_call(a.fasta, a.alignments, out_dir=a.out_dir, prefix=a.prefix, opts=opts, device=local,
-                       streams=a.streams, dist=dist, torch_device=dev)
+                       streams=a.streams, dist=dist, torch_device=dev, pool=pool)
+    if pool is not None:
+        pool.close()
     if full is not None:
         with open(os.path.join(a.out_dir, "%s.filtered.fa" % a.prefix), "w") as f:
             f.write(seqtk_L(full, 400))            # rambl.py:236-238
