@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/config4_full_* from the REFERENCE itself (oracle/_ref/StrainCall_ref, build
+container only): BASELINE.json configs[3] at its stated size -- 1 000 000 x 150 bp reads, 50 strains, one
+1 500 bp gene (rambl_amd.synth.make_gene(4, n_strains=50, n_reads=1000000, name="deep4m")).
+
+  config4_full_D800    rambl.py's -D 800: depth 100 000 thinned to ~8 000 reads before any graph work
+  config4_full_D3000   a raised -D: ~30 000 reads reach the graph, 3 000 read copies per level, 13 sweeps
+
+Why not -D 100000 (SURVEY.md section 8(d) suggested it): the reference's edge support
+(number_of_reads_cover_nodes, PartialOrderGraph.cpp:1218-1244) is a nested loop over two read pools and is
+called per candidate, out-edge and level; at depth 100 000 that is ~1e10 comparisons per call and ~1e15 in
+total, which the reference cannot finish (days).  -D 3000 is the largest depth it finishes in about an hour.
+
+Only the inputs' digests, the argv and the reference's stdout are stored.
+usage: python tests/golden/make_golden_config4.py D [D ...]     (runs the given depths concurrently)
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import sc_testlib as T  # noqa: E402
+from rambl_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "StrainCall_ref")
+WORK = os.path.join(HERE, "_config4_work")
+GEN = 'rambl_amd.synth.make_gene(4, glen=1500, n_strains=50, n_reads=1000000, name="deep4m") + write_dataset'
+
+
+def sha(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def dataset(outdir):
+    gene = synth.make_gene(4, glen=1500, n_strains=50, n_reads=1000000, name="deep4m")
+    return synth.write_dataset(outdir, [gene])
+
+
+def one(job):
+    depth, fa, sam, digests = job
+    argv = ["-r", "deep4m:1-1500", "-q", "0", "-D", str(depth), "-I", "13", "-l", "70", "-t", "0.02", "-d", "0.02", "-w", "5000"]
+    cwd = os.path.join(WORK, "cwd_D%d" % depth)
+    os.makedirs(cwd, exist_ok=True)
+    env = dict(os.environ)
+    env["PATH"] = T.TOOLS + os.pathsep + env.get("PATH", "")
+    env["TMPDIR"] = cwd
+    t0 = time.time()
+    p = subprocess.run([REF] + argv + [fa, sam], cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    dt = int(time.time() - t0)
+    assert p.returncode == 0, (depth, p.returncode)
+    out = os.path.join(HERE, "config4_full_D%d" % depth)
+    os.makedirs(out, exist_ok=True)
+    open(os.path.join(out, "expected.fa"), "wb").write(p.stdout)
+    json.dump(dict(argv=argv, generator=GEN, note="BASELINE.json configs[3] at full size (1 000 000 reads); stdout of the reference itself",
+                   reference_build="oracle/_ref/StrainCall_ref (-O2, s=0)", reference_seconds_build_container=dt, **digests),
+              open(os.path.join(out, "meta.json"), "w"), indent=1, sort_keys=True)
+    return depth, p.stdout.count(b">"), dt
+
+
+def main():
+    depths = [int(x) for x in sys.argv[1:]] or [800, 3000]
+    data = os.path.join(WORK, "data")
+    fa, sam = os.path.join(data, "seed_otus.fasta"), os.path.join(data, "reads.sam")
+    if not (os.path.exists(fa) and os.path.exists(sam)):
+        dataset(data)
+    digests = dict(fasta_sha256=sha(fa), sam_sha256=sha(sam))
+    with ThreadPoolExecutor(len(depths)) as ex:
+        for depth, n, dt in ex.map(one, [(d, fa, sam, digests) for d in depths]):
+            print("config4_full_D%d: %d contigs, %d s" % (depth, n, dt), flush=True)
+
+
+if __name__ == "__main__":
+    main()
