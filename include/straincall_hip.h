@@ -71,6 +71,8 @@ typedef struct sc_stats {
     long chain_passes;        /* window passes of the sampler chain (draws / passes = draws accepted per pass) */
     long chain_cycles;        /* shader cycles spent inside the urn chains */
     long chain_wall_ticks;    /* the same in 100 MHz ticks */
+    long level_kernel_ticks;  /* 100 MHz ticks inside the level kernels (start of the kernel to its completion stamp) */
+    long xcd_levels[8];       /* level kernels that ran on each of the 8 XCDs (HW_REG_XCC_ID) */
     long msa_calls;
     int n_nodes, n_levels, n_unique_reads;
     long n_read_copies;

@@ -11,6 +11,9 @@
 // HBM.
 #include <hip/hip_runtime.h>
 
+#include <sys/prctl.h>
+#include <time.h>
+
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -36,8 +39,9 @@ namespace sc {
 void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node, const int* pool_ptr, const int* pool_rid,
                          const int* pool_cn, const uint8_t* node_is_end, const int* edge_src, int n_edges, int sorted,
                          int* support);
-void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, const LevelParams& H, int do_update);
-void launch_chain(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int S, int Q);
+bool level_wants_grid(const JobDev& job, const LevelHdr& h);
+int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* Pd);
+void launch_level(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* P, LevelResult* R);
 void launch_msa(hipStream_t st, const MsaDev& d);
 void launch_thread(hipStream_t st, const ThreadDev& d, int* pool_sorted);
 int init_kernels();
@@ -152,20 +156,45 @@ struct Ctx {
     std::vector<std::unique_ptr<Worker>> workers;
     double* dU = nullptr;             // uniform stream on the device
     float* dUf = nullptr;             // fp32 copy
-    bool blocking_sync = false;       // workers sleep in the per-level wait instead of spinning
+    int wait_mode = 0;                // how a worker waits for its level's stamp: WAIT_*
 };
+enum { WAIT_SPIN = 0, WAIT_SLEEP = 1, WAIT_EVENT = 2 };
+
+// CPUs this process may use: the cgroup quota when there is one (a GPU box hands out a share of its host)
+static double cpu_budget() {
+    double n = (double)std::thread::hardware_concurrency();
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[64] = {0};
+        double period = 0;
+        if (fscanf(f, "%63s %lf", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+            const double q = atof(quota) / period;
+            if (q > 0 && (n <= 0 || q < n)) n = q;
+        }
+        fclose(f);
+    }
+    return n > 0 ? n : 1;
+}
+static void sleep_us(double us) {
+    if (us <= 0) return;
+    timespec ts;
+    ts.tv_sec = (time_t)(us * 1e-6);
+    ts.tv_nsec = (long)((us - 1e6 * (double)ts.tv_sec) * 1e3);
+    nanosleep(&ts, nullptr);
+}
 
 struct Worker {
     Ctx* ctx;
     std::thread th;
     hipStream_t st = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
-    LevelParams* Ph = nullptr;        // pinned staging
-    LevelParams* Pd = nullptr;
-    LevelResult* Rh = nullptr;        // host-mapped, written by the kernel
+    LevelParams* Ph = nullptr;        // host-mapped: written here, read by the level's kernel over PCIe
+    LevelParams* Pm = nullptr;        //   its device address
+    LevelParams* Pd = nullptr;        // device copy, only for the grid kernels of very large levels
+    LevelResult* Rh = nullptr;        // host-mapped, written by the kernel, stamped last
     LevelResult* Rd = nullptr;
+    unsigned seq = 0;                 // stamp of the last level launched
     DevBuf b_ent_rid, b_ent_cn, b_ent_lab_off, b_ent_lab_len, b_ent_first, b_ent_qoff, b_labels, b_mate_ptr, b_mate_idx,
-        b_ll, b_has, b_isnew, b_tabA, b_tabL, b_tabLf, b_qflag, b_qcode, b_qent, b_quid, b_out_ptr, b_out_node, b_pool_ptr, b_pool_rid,
+        b_ll, b_has, b_isnew, b_tabA, b_tabLf, b_qcode, b_qent, b_quid, b_out_ptr, b_out_node, b_pool_ptr, b_pool_rid,
         b_pool_cn, b_isend, b_esrc, b_support;
     DevBuf m_seqs, m_off, m_cols0, m_cols1, m_counts, m_moves, m_trace, m_out;
     DevBuf t_ref, t_pos, t_seqoff, t_seq, t_cigoff, t_cigop, t_ciglen, t_lut, t_tabs, t_pool, t_pool2;
@@ -173,6 +202,8 @@ struct Worker {
     void init();
     void run();
     void process(Job& job);
+    void wait_level(unsigned want, double predicted_us);
+    double ns_per_draw = 0, plain_level_us = 0;      // what the last levels took, to size the sleep of WAIT_SLEEP
     int msa_device(const std::vector<std::string>& seqs, std::vector<std::string>& rows);
     void thread_device(const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cig,
                        ThreadTables& T);
@@ -185,10 +216,48 @@ void Worker::init() {
     HIPCHK(hipEventCreate(&ev0));
     HIPCHK(hipEventCreate(&ev1));
     HIPCHK(hipEventCreateWithFlags(&ev_sync, hipEventBlockingSync | hipEventDisableTiming));
-    HIPCHK(hipHostMalloc((void**)&Ph, sizeof(LevelParams), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&Ph, sizeof(LevelParams), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&Pm, Ph, 0));
     HIPCHK(hipMalloc((void**)&Pd, sizeof(LevelParams)));
-    HIPCHK(hipHostMalloc((void**)&Rh, sizeof(LevelResult), hipHostMallocMapped));
+    HIPCHK(hipHostMalloc((void**)&Rh, sizeof(LevelResult), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&Rd, Rh, 0));
+    std::memset(Rh, 0, sizeof(LevelResult));
+}
+
+// The level's kernel stores its stamp into host memory after everything else it reports (system-scope
+// release): the host sees the level finished without a stream synchronisation.  With more regions in flight
+// than cores, sleep on an event instead of spinning.
+void Worker::wait_level(unsigned want, double predicted_us) {
+    auto done = [&] { return __atomic_load_n(&Rh->seq, __ATOMIC_ACQUIRE) == want; };
+    auto check_stream = [&] {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) {
+            if (!done()) throw HipError("a level kernel ended without its completion stamp");
+        } else if (e != hipErrorNotReady) {
+            throw HipError(std::string("level kernel: ") + hipGetErrorString(e));
+        }
+    };
+    if (ctx->wait_mode == WAIT_EVENT) {
+        HIPCHK(hipEventRecord(ev_sync, st));
+        HIPCHK(hipEventSynchronize(ev_sync));
+        if (!done()) throw HipError("a level kernel ended without its completion stamp");
+        return;
+    }
+    if (ctx->wait_mode == WAIT_SLEEP) {
+        // more regions in flight than this process has cores: sleep through most of the level, then look every few tens of microseconds
+        if (predicted_us > 80) sleep_us(0.85 * predicted_us - 20);
+        unsigned polls = 0;
+        while (!done()) {
+            sleep_us(20);
+            if ((++polls & 0x3FFu) == 0) check_stream();
+        }
+        return;
+    }
+    unsigned spins = 0;
+    while (!done()) {
+        __builtin_ia32_pause();
+        if ((++spins & 0x3FFFFu) == 0) check_stream();   // every few milliseconds: has the stream died?
+    }
 }
 
 // a7 on the device.  Returns the number of columns.
@@ -377,9 +446,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     jd.isnew = (uint8_t*)b_isnew.ensure((size_t)max_level_entries + 8);
     jd.qcap = qcap;
     jd.tabA = (double*)b_tabA.ensure(sizeof(double) * (size_t)qcap * MAXS);
-    jd.qmax = (double*)b_tabL.ensure(sizeof(double) * (size_t)qcap);
     jd.tabLf = (float*)b_tabLf.ensure(sizeof(float) * (size_t)(std::min<long>(qcap, MAX_DRAWS) + 4) * 136);
-    jd.qflag = (uint8_t*)b_qflag.ensure((size_t)qcap + 8);
     jd.qcode = (uint8_t*)b_qcode.ensure((size_t)qcap + 8);
     jd.qent = (int*)b_qent.ensure(sizeof(int) * (size_t)qcap);
     jd.quid = (int*)b_quid.ensure(sizeof(int) * (size_t)qcap);
@@ -463,26 +530,29 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     std::vector<std::pair<int, int>> pending_copies;     // (src slot, dst slot) for the next launch
     double sampler_ms = 0;
     long sampler_launches = 0, level_launches = 0, draws = 0, exact = 0, slow = 0, sampler_copies = 0, sampler_strains = 0, passes = 0;
-    unsigned long long chain_cycles = 0, chain_wall = 0;
+    unsigned long long chain_cycles = 0, chain_wall = 0, level_ticks = 0;
 
     FILE* level_log = getenv("SC_LEVEL_LOG") ? fopen(getenv("SC_LEVEL_LOG"), "a") : nullptr;   // diagnostics only
     auto run_level = [&](int mode, int e0, int e1, int Q, int n_sweeps, bool do_update, const std::vector<HStrain>& sv,
                          bool has_dups, bool any_multi) {
         LevelParams& P = *Ph;
         const int S = (int)sv.size();
-        P.mode = mode; P.S = S; P.e0 = e0; P.e1 = e1; P.has_dups = has_dups; P.any_multi = any_multi; P.Q = Q;
-        P.n_sweeps = n_sweeps;
-        P.n_copy = (int)pending_copies.size();
-        for (int c = 0; c < P.n_copy; c++) { P.copy_src[c] = pending_copies[c].first; P.copy_dst[c] = pending_copies[c].second; }
+        LevelHdr H{};
+        H.mode = mode; H.S = S; H.e0 = e0; H.e1 = e1; H.has_dups = has_dups; H.any_multi = any_multi; H.Q = Q;
+        H.n_sweeps = n_sweeps; H.do_update = do_update ? 1 : 0;
+        H.n_copy = (int)pending_copies.size();
+        for (int c = 0; c < H.n_copy; c++) { P.copy_src[c] = pending_copies[c].first; P.copy_dst[c] = pending_copies[c].second; }
         pending_copies.clear();
         ld za = 0;
         for (int s = 0; s < S; s++) za += sv[s].abundance;                 // normalize(), :10-15
         for (int s = 0; s < S; s++) {
-            P.slot[s] = sv[s].slot;
-            P.lab_off[s] = sv[s].node >= 0 ? f.node_lab_off[sv[s].node] : 0;
-            P.lab_len[s] = sv[s].node >= 0 ? f.node_lab_len[sv[s].node] : 0;
-            P.a0[s] = (double)sv[s].abundance;
-            P.logpri[s] = (double)logl(sv[s].abundance / za);
+            StrainParam& sp = P.sp[s];
+            sp.slot = sv[s].slot;
+            sp.lab_off = sv[s].node >= 0 ? f.node_lab_off[sv[s].node] : 0;
+            sp.lab_len = sv[s].node >= 0 ? f.node_lab_len[sv[s].node] : 0;
+            sp.pad = 0;
+            sp.a0 = (double)sv[s].abundance;
+            sp.logpri = (double)logl(sv[s].abundance / za);
             // log table of the strain: only the rows its counts changed in since the last level are recomputed
             HStrain& hs = const_cast<HStrain&>(sv[s]);
             for (int a = 0; a < KMAX; a++) {
@@ -491,36 +561,38 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 for (int b = 0; b < KMAX; b++) hs.lpc[a * KMAX + b] = (a < K && b < K) ? (double)(logl(hs.sub[a * KMAX + b]) - lc) : 0.0;
             }
             hs.dirty = 0;
-            std::memcpy(P.lpt + (size_t)s * KK, hs.lpc, sizeof(double) * KK);
+            if (do_update) std::memcpy(P.lpt + (size_t)s * KK, hs.lpc, sizeof(double) * KK);
         }
-        const size_t bytes = offsetof(LevelParams, lpt) + sizeof(double) * (size_t)S * KK;
-        HIPCHK(hipMemcpyAsync(Pd, Ph, bytes, hipMemcpyHostToDevice, st));
         const bool chain = (mode == MODE_SAMPLE) && S > 1 && n_sweeps > 0;
         const bool timed = chain && pa.want_timing;
-        launch_level(st, jd, Pd, Rd, P, do_update ? 1 : 0);
-        if (chain) {
-            if (timed) HIPCHK(hipEventRecord(ev0, st));
-            launch_chain(st, jd, Pd, Rd, S, Q);
-            if (timed) HIPCHK(hipEventRecord(ev1, st));
+        if (level_wants_grid(jd, H)) {
+            // a very large level: row copies / the single-symbol update on a grid, from a device copy of the parameters
+            const size_t bytes = offsetof(LevelParams, lpt) + sizeof(double) * (size_t)S * KK;
+            HIPCHK(hipMemcpyAsync(Pd, Ph, bytes, hipMemcpyHostToDevice, st));
+            H.done = launch_level_grid(st, jd, H, Pd);
         }
-        if (ctx->blocking_sync) {
-            // more regions in flight than host cores can spin for: sleep until the level is done
-            HIPCHK(hipEventRecord(ev_sync, st));
-            HIPCHK(hipEventSynchronize(ev_sync));
-        } else {
-            HIPCHK(hipStreamSynchronize(st));
-        }
+        H.seq = ++seq;
+        if (timed) HIPCHK(hipEventRecord(ev0, st));
+        launch_level(st, jd, H, Pm, Rd);
+        if (timed) HIPCHK(hipEventRecord(ev1, st));
+        wait_level(H.seq, chain ? ns_per_draw * 1e-3 * (double)n_sweeps * Q : plain_level_us);
+        if (chain && n_sweeps * Q > 0) ns_per_draw = 10.0 * (double)Rh->level_wall / ((double)n_sweeps * Q);
+        else plain_level_us = 0.01 * (double)Rh->level_wall;
+        if (timed) HIPCHK(hipEventSynchronize(ev1));
         level_launches++;
         if (chain) {
             sampler_launches++; sampler_copies += Q;
             draws += (long)Rh->n_draws; exact += (long)Rh->n_exact; slow += (long)Rh->n_slow; sampler_strains += S; passes += (long)Rh->n_pass;
             chain_cycles += Rh->chain_cycles; chain_wall += Rh->chain_wall;
         }
+        level_ticks += Rh->level_wall;
+        if (level_log) fprintf(level_log, "h %d mode %d S %d Q %d n %d level_us %.1f chain_us %.1f cyc %llu passes %llu slow %llu xcc %d\n", job.handle, mode, S, Q,
+                               n_sweeps, Rh->level_wall * 0.01, chain ? Rh->chain_wall * 0.01 : 0.0, chain ? (unsigned long long)Rh->chain_cycles : 0ull,
+                               chain ? (unsigned long long)Rh->n_pass : 0ull, chain ? (unsigned long long)Rh->n_slow : 0ull, Rh->xcc);
+        job.stats.xcd_levels[Rh->xcc & 7]++;
         if (timed) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
-            if (level_log) fprintf(level_log, "S %d Q %d n %d ms %.4f passes %llu slow %llu cyc %llu\n", S, Q, n_sweeps, ms,
-                                   (unsigned long long)Rh->n_pass, (unsigned long long)Rh->n_slow, (unsigned long long)Rh->chain_cycles);
             sampler_ms += ms;
         }
     };
@@ -599,7 +671,8 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                     }
                 } else {
                     for (int s = 0; s < S; s++) {
-                        a[s] = level_strains[s].abundance + (ld)Rh->kdraw[s];      // a[c] += 1 per draw, :195
+                        a[s] = level_strains[s].abundance;
+                        for (unsigned t = 0; t < Rh->kdraw[s]; t++) a[s] += 1;     // a[c] += 1 per draw, :195 (one rounding per draw)
                         for (int b = 0; b < KMAX; b++) cnt[s][b] = (ld)Rh->cnt[s * KMAX + b];
                     }
                 }
@@ -724,7 +797,10 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         } else {
             pending_copies.clear();
             run_level(MODE_SAMPLE, final_e0, final_e0 + n_reads, Q, n, false, fs, false, true);
-            for (int s = 0; s < S; s++) a[s] = fs[s].abundance + (ld)Rh->kdraw[s];
+            for (int s = 0; s < S; s++) {
+                a[s] = fs[s].abundance;
+                for (unsigned t = 0; t < Rh->kdraw[s]; t++) a[s] += 1;             // :823, one rounding per draw
+            }
         }
         ld z = 0;
         for (int s = 0; s < S; s++) z += a[s];
@@ -754,6 +830,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     job.stats.chain_cycles = (long)chain_cycles;
     job.stats.chain_wall_ticks = (long)chain_wall;
     job.stats.sampler_strains = sampler_strains;
+    job.stats.level_kernel_ticks = (long)level_ticks;
 }
 
 void Worker::process(Job& job) {
@@ -785,6 +862,7 @@ void Worker::process(Job& job) {
 }
 
 void Worker::run() {
+    prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0);          // nanosleep of WAIT_SLEEP: wake within ~2 us of the timer, not the default 50
     try { init(); } catch (const std::exception& ex) {
         std::lock_guard<std::mutex> lk(ctx->mu);
         ctx->last_error = ex.what();
@@ -852,9 +930,12 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
     if (stream_count < 1) stream_count = 1;
     if (stream_count > 64) stream_count = 64;
     {
-        const unsigned cores = std::thread::hardware_concurrency();
-        const char* e = getenv("SC_BLOCKING_SYNC");
-        ctx->blocking_sync = e ? (atoi(e) != 0) : (cores > 0 && (unsigned)stream_count + 1 > cores);
+        // spinning workers see their level's stamp at once, but only while every one of them has a core
+        const char* e = getenv("SC_WAIT");
+        if (e && !std::strcmp(e, "spin")) ctx->wait_mode = WAIT_SPIN;
+        else if (e && !std::strcmp(e, "sleep")) ctx->wait_mode = WAIT_SLEEP;
+        else if (e && !std::strcmp(e, "event")) ctx->wait_mode = WAIT_EVENT;
+        else ctx->wait_mode = ((double)stream_count + 2 <= 0.6 * cpu_budget()) ? WAIT_SPIN : WAIT_SLEEP;
     }
     for (int i = 0; i < stream_count; i++) {
         auto w = std::make_unique<Worker>();
@@ -901,6 +982,14 @@ int sc_roi_submit(sc_ctx* h, const char* ref_bases, int ref_len, const int* read
                   const int* mate_idx, const int* mate_off, int n_reads, const sc_params* params, int* handle_out) {
     if (!h || !ref_bases || ref_len < 0 || n_reads < 0 || !params || !handle_out) return SC_ERR_ARG;
     if (n_reads > 0 && (!read_pos || !cigar_text || !cigar_off || !seq_text || !seq_off || !read_copies || !mate_off)) return SC_ERR_ARG;
+    // the device buffers are sized for the reference's literals (uniform stream of MAX_DRAWS values, MAXS rows)
+    if (params->draw_budget < 1 || params->draw_budget > MAX_DRAWS || params->sweeps_cap < 0 || params->max_candidates < 1 ||
+        params->max_candidates > MAXS)
+        return SC_ERR_ARG;
+    if (n_reads > 0 && (cigar_off[0] < 0 || seq_off[0] < 0 || mate_off[0] != 0)) return SC_ERR_ARG;
+    for (int i = 0; i < n_reads; i++)
+        if (read_copies[i] < 1 || cigar_off[i + 1] < cigar_off[i] || seq_off[i + 1] < seq_off[i] || mate_off[i + 1] < mate_off[i])
+            return SC_ERR_ARG;
     auto job = std::make_shared<Job>();
     job->ref.assign(ref_bases, (size_t)ref_len);
     job->reads.resize((size_t)n_reads);

@@ -37,19 +37,19 @@ struct JobDev {
     const float* Uf;             // the same stream rounded to fp32 (first tier of the sampler)
     // scratch
     uint8_t* isnew;              // [max entries per level]
-    double* tabA;                // [MAXS][qcap]  LLq / P  (strain-major)
-    double* qmax;                // [qcap] max over strains of the draw slot's log-likelihood
-    float* tabLf;                // [qcap][SPAD]  sampler weights, fp32, when they do not fit in LDS
-    uint8_t* qflag;              // [qcap] exact-path flag per draw slot
+    double* tabA;                // [MAXS][qcap]  responsibilities of the soft update (strain-major)
+    float* tabLf;                // [qcap][stride]  sampler weights, fp32, when they do not fit in LDS
     uint8_t* qcode;              // [qcap] read-label symbol code of a draw slot (0xFF: not a single symbol)
     int* qent;                   // [qcap] entry index of a draw slot
     int* quid;                   // [qcap] mate read id of a draw slot (-1 none)
     long qcap;
 };
 
-// Per-level parameters: staged by the host in pinned memory and copied to the
-// device in front of the launch (only the first S rows of `lpt`, which is last).
-struct LevelParams {
+// Per-level parameters.  The scalars travel as kernel arguments (LevelHdr); the per-strain part lives
+// in host-mapped pinned memory that the kernel of the level reads directly over PCIe, once, into LDS
+// (no copy in front of the launch).  Only the first h.S entries of `sp` / rows of `lpt` and the first
+// h.n_copy copy pairs are read.
+struct LevelHdr {
     int mode;
     int S;                       // strains at this level
     int e0, e1;                  // entry range
@@ -58,15 +58,24 @@ struct LevelParams {
     int Q;                       // read_size = sum of copy numbers
     int n_sweeps;                // min(5000, 40000/Q)
     int n_copy;                  // row copies to perform first
+    int do_update;               // apply the level's read log-likelihood update (not for read_assign)
+    int done;                    // LV_* pieces already run by grid kernels (very large levels only)
+    unsigned seq;                // completion stamp the kernel stores into LevelResult::seq when it is done
+};
+struct StrainParam {
+    int slot;                    // ll row of the strain
+    int lab_off, lab_len;        // node label of the strain (into labels)
+    int pad;
+    double a0;                   // abundance before clustering
+    double logpri;               // log(a_s / sum a) for the hard update
+};
+struct LevelParams {
     int copy_src[MAXS], copy_dst[MAXS];
-    int slot[MAXS];              // ll row of strain s
-    int lab_off[MAXS], lab_len[MAXS];   // node label of strain s (into labels)
-    double a0[MAXS];             // abundance before clustering
-    double logpri[MAXS];         // log(a_s / sum a) for the hard update
+    StrainParam sp[MAXS];
     double lpt[MAXS * KK];       // log sub(a,b) - log comp(a) per strain
 };
 
-// Per-level results, written by the kernel into pinned memory.
+// Per-level results, written by the kernel into host-mapped pinned memory; `seq` last (system-scope release).
 struct LevelResult {
     double abund[MAXS];          // HARD: sum of responsibilities; SAMPLE: urn weights a[] after the sweeps
     double subst[MAXS * KK];     // HARD: responsibility-weighted substitution counts
@@ -77,7 +86,10 @@ struct LevelResult {
     unsigned long long n_pass;   // window passes of the sampler chain
     unsigned long long chain_cycles, chain_wall;   // shader cycles / 100 MHz ticks spent in the urn chain
     unsigned long long n_exact;  // draws resolved by the literal fp64 path
+    unsigned long long level_wall;                 // 100 MHz ticks from the start of the level's kernel to its end
     int error;
+    int xcc;                     // XCD the level's workgroup ran on (HW_REG_XCC_ID)
+    unsigned seq;                // == LevelHdr::seq once every other field is in place
 };
 
 // Buffers of the read-threading kernels (k_thread_*).

@@ -3,11 +3,13 @@
 //   k_thread_*       threading of the reads along the backbone                 (row a5)
 //   k_msa            progressive sum-of-pairs MSA of insertion strings          (a7, a8)
 //   k_edge_support   number_of_reads_cover_nodes for every edge                (a16)
-//   k_level_*        per-level read log-likelihood update, draw slots and the
-//                    sampler's tables on a grid (a13); k_level: the order-
-//                    dependent rest and the soft update (a15, hard_clustering)
-//   k_chain_w        the Polya-urn sampler of one level (a14, np_bayes_clustering;
-//                    also a18, read_assign)
+//   k_level_sample   one sampler level in one launch: rows of new strains, read
+//                    log-likelihood update (a13), draw slots and weight rows, and
+//                    the Polya-urn chain (a14, np_bayes_clustering; also a18,
+//                    read_assign)
+//   k_level          one level without the sampler: the update (a13) and the soft
+//                    update (a15, hard_clustering)
+//   k_level_copy/update   the first two pieces on a grid, for very large levels
 //
 // These are integer / fp32 / fp64 loops bound by latency or HBM: no MFMA.  The
 // sampler is one dependent chain per region; four or eight wavefronts speculate
@@ -27,9 +29,9 @@ namespace sc {
 #define SC_LDS __attribute__((address_space(3)))
 
 constexpr int LDS_TOTAL = 160 * 1024 - 256;   // dynamic part; the rest covers small static __shared__ variables
-constexpr int LDS_SMALL = 9 * 1024;            // per-strain scalars
+constexpr int LDS_SMALL = 13 * 1024;           // per-strain scalars (LevelLds)
 constexpr int LDS_BIG = LDS_TOTAL - LDS_SMALL;
-static_assert(LDS_SMALL >= (int)(sizeof(double) * 3 * MAXS + sizeof(unsigned) * MAXS * KMAX + sizeof(int) * 3 * MAXS + 64), "LDS_SMALL");
+static_assert(LDS_SMALL >= (int)(sizeof(double) * 2 * MAXS + sizeof(StrainParam) * MAXS + sizeof(unsigned) * MAXS * KMAX + sizeof(int) * 5 * MAXS + 64), "LDS_SMALL");
 static_assert(LDS_BIG >= (int)(sizeof(double) * MAXS * KK), "LDS_BIG");
 
 // --------------------------------------------------------------------------
@@ -108,8 +110,7 @@ __global__ __launch_bounds__(256) void k_edge_support(const int* __restrict__ ou
 // discrete_distribution): executed by lane 0 of the sampling wave for the rare
 // draw whose uniform lies within the safety margin of a boundary.
 struct SlowArgs {          // the few JobDev fields the rare tiers need, passed by value
-    const double* tabA; const double* qmax; long qcap; const uint8_t* qflag; const int* qent; const int* quid;
-    const int* ent_rid; const double* ll; long ll_stride; const uint8_t* has;
+    const int* qent; const int* quid; const int* ent_rid; const double* ll; long ll_stride; const uint8_t* has;
 };
 __device__ int exact_draw(const SlowArgs job, const int* s_slot, const volatile double* s_a,
                           volatile double* s_p, int S, int rid, int uid, double u) {
@@ -144,26 +145,44 @@ __device__ int exact_draw(const SlowArgs job, const int* s_slot, const volatile 
 constexpr double DRAW_EPS64 = 1e-10;  // margin (relative to the total weight) of the fp64 scan tier
 
 // Tier 2 and 3 of one draw: fp64 weights and scan with a 1e-10 margin; if the
-// uniform is still within the margin of a boundary (or the slot is flagged for
-// underflow), the literal evaluation.  Wave-uniform call.
+// uniform is still within the margin of a boundary (or the slot's log-likelihoods
+// lie in the underflow range of the reference's exp), the literal evaluation.
+// The slot's log-likelihoods are re-read from the rows (the table kept only their
+// fp32 weights).  Wave-uniform call.
 template <int NPL>
 __device__ __noinline__ int slow_draw(const SlowArgs job, const int* s_slot, volatile double* s_a, volatile double* s_p,
                                       double a0, double a1, int S, int q, int e0, double u, int lane) {
     const double a[2] = {a0, a1};
-    double w[NPL], pair = 0;
-    const double m = job.qmax[q];
+    const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
+    const bool hr = job.has[rid] != 0, hu = uid >= 0 && job.has[uid] != 0;
+    double x[NPL], m = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NPL; i++) {
         const int s = lane * NPL + i;
-        // fp64 weight a_s * exp(loglik - max), rebuilt from the strain-major table on demand
-        w[i] = (s < S) ? a[i] * exp(job.tabA[(long)s * job.qcap + q] - m) : 0.0;
+        x[i] = -INFINITY;
+        if (s < S) {
+            const double* row = job.ll + (long)s_slot[s] * job.ll_stride;
+            double v = hr ? row[rid] : 0.0;
+            if (hu) v += row[uid];
+            x[i] = v;
+            m = fmax(m, v);
+        }
+    }
+    for (int d = 1; d < 64; d <<= 1) m = fmax(m, __shfl_xor(m, d));
+    const bool flag = !(m >= -600.0);                     // underflow range of the reference's exp(); also NaN / -inf
+    double w[NPL], pair = 0;
+#pragma unroll
+    for (int i = 0; i < NPL; i++) {
+        const int s = lane * NPL + i;
+        // fp64 weight a_s * exp(loglik - max)
+        w[i] = (s < S) ? a[i] * exp(x[i] - m) : 0.0;
         pair += w[i];
     }
     const double incl = wave_scan_incl(pair);
     const double T = readlane_f64(incl, 63);
     const double tgt = u * T;
     const double lo = tgt - DRAW_EPS64 * T, hi = tgt + DRAW_EPS64 * T;
-    bool ok = (T > 0.0) && (T < 1.0e300) && !job.qflag[q];
+    bool ok = (T > 0.0) && (T < 1.0e300) && !flag;
     int c;
     if (NPL == 1) {
         const unsigned long long mlo = __ballot(incl >= lo), mhi = __ballot(incl >= hi);
@@ -183,7 +202,7 @@ __device__ __noinline__ int slow_draw(const SlowArgs job, const int* s_slot, vol
         for (int i = 0; i < NPL; i++) { int s = lane * NPL + i; if (s < S) s_a[s] = a[i]; }
         __builtin_amdgcn_wave_barrier();
         int cc = 0;
-        if (lane == 0) cc = exact_draw(job, s_slot, s_a, s_p, S, job.ent_rid[e0 + job.qent[q]], job.quid[q], u);
+        if (lane == 0) cc = exact_draw(job, s_slot, s_a, s_p, S, rid, uid, u);
         c = __builtin_amdgcn_readfirstlane(cc);
         __builtin_amdgcn_wave_barrier();
         c |= 0x100;                                    // tell the caller the literal tier ran
@@ -193,24 +212,30 @@ __device__ __noinline__ int slow_draw(const SlowArgs job, const int* s_slot, vol
 
 // --------------------------------------------------------------------------
 // Wide urn chain: a sliding window of 64 draws over the four wavefronts of the
-// workgroup (one per SIMD), four lanes per draw.
+// workgroup (one per SIMD), four lanes per draw (128 draws on eight wavefronts
+// while a lane owns at most 8 strains).
 //
 // Draw t+p of a pass (p = 0..63) belongs to the quad of lanes 4*(p%16)..+3 of
 // wave p/16; lane k of the quad walks its quarter of the strains in order with
 // the counts as they are in front of draw t (uniform over the draws), one FMA
 // per strain: cum_s = sum_{s'<=s} (a0_s' + k_s') * L[q][s'].  The quarters are
 // joined inside the quad by DPP (totals -> offsets and T, then the number of
-// boundaries below u*T and the distance to the nearest one).  The p draws in
-// front of draw t+p can move any cum_s - u*T by at most p (every L <= 1 and each
-// draw adds one to one count), so its decision is FINAL whenever no boundary lies
-// within (eps*T + p) of u*T -- whatever the earlier draws of the window turn out
-// to be.  Each pass accepts the draws in front of the first one that fails this
-// test (one LDS float atomic per accepted draw; the waves exchange the position
-// through LDS) and the window moves on to that draw, which then has p = 0 and
-// margin eps*T only.  A draw that fails at p = 0 is within the fp32 error bound
-// of a boundary (or its slot is flagged): wave 0 sends it through the fp64 scan
-// and, if needed, the literal evaluation.  eps bounds the fp32 error of the
-// chains and sums, < (2*S + 9) * 2^-24 relative to T.
+// boundaries below u*T and the distances to the nearest boundary on either side).
+//
+// Why a speculative decision is final.  Let d_s = cum_s - u*T.  Each of the p
+// draws in front of draw t+p adds one to one count c_j, which adds L[c_j] <= 1
+// to T and to every cum_s with s >= c_j: d_s moves by L[c_j]*([c_j <= s] - u),
+// i.e. up by at most (1-u) and down by at most u per earlier draw.  So a boundary
+// below the target (d_s < 0) stays below it if -d_s > (1-u)*p and one at or above
+// it (d_s >= 0) stays there if d_s > u*p -- whatever the earlier draws of the
+// window turn out to be.  The test adds eps*T on both sides for the fp32 error of
+// the chains and sums (< (2*S + 9) * 2^-24 relative to T).  Each pass accepts the
+// draws in front of the first one that fails the test (one LDS integer atomic per
+// accepted draw; the waves exchange the position through LDS) and the window
+// moves on to that draw, which then has p = 0 and margin eps*T only.  A draw that
+// fails at p = 0 is within the fp32 error bound of a boundary (or its row is NaN:
+// flagged slot): wave 0 sends it through the fp64 scan and, if needed, the literal
+// evaluation.
 //
 // Weight rows are row-major [Q][stride] fp32, stride = 4 * odd.
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -228,9 +253,11 @@ __device__ __forceinline__ f2v pk_sub(f2v a, f2v b) {
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
-__device__ __forceinline__ float min3_abs(float m, float x, float y) {
-    float d;
-    asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(d) : "v"(m), "v"(x), "v"(y));
+// min over the raw bits as unsigned integers: among floats, the smallest non-negative one (a negative float has
+// the sign bit set and compares above every non-negative float)
+__device__ __forceinline__ unsigned min3_u32(unsigned m, unsigned x, unsigned y) {
+    unsigned d;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(x), "v"(y));
     return d;
 }
 template <int QP> __device__ __forceinline__ float quad_f32(float v) {     // quad_perm DPP
@@ -245,18 +272,17 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 constexpr int UWIN = 1024;     // uniforms staged in LDS (fp32), refilled in halves
 
 template <int NQ, bool ROWS_LDS, int NW>
-__device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
+__device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelHdr& h, const StrainParam* s_sp, LevelResult* __restrict__ R,
                                             const int* s_slot, volatile double* s_a, volatile double* s_p, unsigned* s_kf,
                                             const float* s_a0f, unsigned* s_cnt, int* s_x, float* s_uwin, const float* rows_lds, int stride, int tid) {
     constexpr int SPL = 4 * NQ, SP = 16 * NQ;               // strains per lane, capacity
     constexpr int NPLC = SP > 64 ? 2 : 1;                  // strains per lane in the checked tier
     constexpr float EPSW = (float)(SP + 12) * 1.5e-7f;
-    constexpr float BIG = 1.0e30f;
     const int lane = tid & 63, wv = tid >> 6, k = lane & 3, pos = wv * 16 + (lane >> 2);
-    const int S = P->S, Q = P->Q, n = P->n_sweeps, e0 = P->e0;
+    const int S = h.S, Q = h.Q, n = h.n_sweeps, e0 = h.e0;
     const int Sm1 = S - 1;
     const int total = n * Q;
-    const SlowArgs sa{job.tabA, job.qmax, job.qcap, job.qflag, job.qent, job.quid, job.ent_rid, job.ll, job.ll_stride, job.has};
+    const SlowArgs sa{job.qent, job.quid, job.ent_rid, job.ll, job.ll_stride, job.has};
     const SC_GLOBAL double* Ustream = (const SC_GLOBAL double*)job.U;
     const SC_GLOBAL float* Uf = (const SC_GLOBAL float*)job.Uf;
     const SC_GLOBAL float* rows_g = (const SC_GLOBAL float*)job.tabLf;
@@ -270,7 +296,7 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
     const float posf = (float)pos + 1.0e-37f;
     double a0m[NPLC];                                       // wave 0, checked tier: strains across the lanes
 #pragma unroll
-    for (int i = 0; i < NPLC; i++) { const int s = lane * NPLC + i; a0m[i] = (s < S) ? P->a0[s] : 0.0; }
+    for (int i = 0; i < NPLC; i++) { const int s = lane * NPLC + i; a0m[i] = (s < S) ? s_sp[s].a0 : 0.0; }
     f4v a0q[NQ];
 #pragma unroll
     for (int g = 0; g < NQ; g++) a0q[g] = *(const f4v*)(s_a0f + cbase + 4 * g);
@@ -324,29 +350,34 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
         const float i2 = fmaf(quad_f32<0x40>(i1), m1, i1);         // + two lanes back              ([0,0,0,1])
         const float off = i2 - run;
         const float T = quad_f32<0xFF>(i2);
-        // position of u*T among the boundaries and the distance to the nearest one
+        // position of u*T among the boundaries and the distance to the nearest one on either side
         const float tgt = uf * T;
         const float tb = tgt - off;
         const f2v tb2 = {tb, tb};
         unsigned w = 0;
-        float dm = BIG;
+        unsigned up = 0x7f800000u, dn = 0x7f800000u;        // +inf: nearest boundary at / above and below the target
 #pragma unroll
         for (int j = 0; j < SPL; j += 2) {
             const f2v lc = {loc[j], loc[j + 1]};
-            const f2v d = pk_sub(lc, tb2);
+            const f2v d = pk_sub(lc, tb2);                   // cum - target
+            const f2v e = pk_sub(tb2, lc);                   // target - cum
             w = __builtin_amdgcn_alignbit(w, __float_as_uint(d.x), 31);   // (w << 1) | sign(d)
             w = __builtin_amdgcn_alignbit(w, __float_as_uint(d.y), 31);
-            dm = min3_abs(dm, d.x, d.y);
+            up = min3_u32(up, __float_as_uint(d.x), __float_as_uint(d.y));
+            dn = min3_u32(dn, __float_as_uint(e.x), __float_as_uint(e.y));
         }
-        // Strains >= S-1 and the padding all sit at cum = T >= u*T.  They never count (a padding entry
-        // can round to a tiny negative difference: the count is clamped), and their distance T - u*T
-        // must not enter the margin test: alt = -(cum_{S-2} - u*T) is <= 0 while a real boundary lies
-        // at or above u*T and is the distance to the nearest real boundary when none does.
-        // (max(min_k dm_k, alt) >= lim  <=>  every lane k of the quad has max(dm_k, alt) >= lim.)
+        // Strains >= S-1 and the padding all sit at cum = T >= u*T: they are no boundaries.  They never count (a
+        // padding entry can round to a tiny negative difference: the count is clamped, and that draw fails the
+        // test below), and their distance T - u*T must not fail a draw whose target lies above the last real
+        // boundary cum_{S-2}: alt = u*T - cum_{S-2} is then positive and IS the distance to the nearest real
+        // boundary; once it clears the lower margin there is nothing above the target to test.
         const float alt = tgt - (T - alast * llast);
-        const float dmin = fmaxf(dm, alt);
-        const float lim = fmaf(EPSW, T, posf);              // NaN (flagged slot) and T == 0 fail the test
-        const unsigned long long F = ~__ballot(dmin >= lim);
+        const float epsT = EPSW * T;
+        const float lim_up = fmaf(uf, posf, epsT);           // a boundary at / above the target moves down by <= u per earlier draw
+        const float lim_dn = fmaf(1.0f - uf, posf, epsT);    // one below it moves up by <= 1 - u
+        // NaN (flagged slot) and T == 0 fail the test
+        const bool okl = (__uint_as_float(dn) >= lim_dn) && ((__uint_as_float(up) >= lim_up) || (alt >= lim_dn));
+        const unsigned long long F = ~__ballot(okl);
         const int fpos = F ? 16 * wv + ((int)__builtin_ctzll(F) >> 2) : 16 * NW;
         if (lane == 0) s_x[wv] = fpos;
         int c = __popc(w);
@@ -428,13 +459,14 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelParams
 }
 
 // --------------------------------------------------------------------------
-// Grid-parallel pieces of one level (the usual case: every label a single symbol, no read twice in
-// the level).  They are plain data-parallel loops over (strain, read) items; k_level keeps the
-// order-dependent parts.
+// The pieces of one level of the walk (NonparametricClustering.cpp:284-458) that every mode shares.  They
+// run inside the level's single workgroup (k_level_sample / k_level); for levels with hundreds of thousands
+// of (strain, read) items the host runs the first two on a grid instead (k_level_copy, k_level_update) and
+// says so in LevelHdr::done.
 enum { LV_COPIES_DONE = 1, LV_ITEMS_DONE = 2 };
 
-// phase 0: rows of strains created by the last extension (Strain copy, Strain.cpp:73-83); copies are
-// independent (a destination row is a free row, a source row a surviving parent's)
+// grid, phase 0: rows of strains created by the last extension (Strain copy, Strain.cpp:73-83); copies are
+// independent (a destination row is a free row, a source row a surviving parent's).  P: device copy.
 __global__ __launch_bounds__(256) void k_level_copy(JobDev job, const LevelParams* __restrict__ P) {
     const int c = blockIdx.y;
     const double2* src = reinterpret_cast<const double2*>(job.ll + (long)P->copy_src[c] * job.ll_stride);
@@ -443,14 +475,14 @@ __global__ __launch_bounds__(256) void k_level_copy(JobDev job, const LevelParam
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-// phase 1, single-symbol labels: ll[s][rid] (+)= log P(read symbol | strain symbol), NonparametricClustering.cpp:343-391
-__global__ __launch_bounds__(256) void k_level_update(JobDev job, const LevelParams* __restrict__ P) {
+// grid, phase 1, single-symbol labels: ll[s][rid] (+)= log P(read symbol | strain symbol), NonparametricClustering.cpp:343-391
+__global__ __launch_bounds__(256) void k_level_update(JobDev job, LevelHdr h, const LevelParams* __restrict__ P) {
     __shared__ double s_row[MAXS * KMAX];       // lpt[s][label of s][b]
     __shared__ double s_diag[MAXS * KMAX];      // lpt[s][b][b]  (an N in the strain label matches the read symbol)
     __shared__ int s_slot[MAXS], s_lab[MAXS];
     const int tid = threadIdx.x;
-    const int S = P->S, K = job.K, e0 = P->e0, Rn = P->e1 - P->e0, codeN = job.code_N;
-    for (int s = tid; s < S; s += blockDim.x) { s_slot[s] = P->slot[s]; s_lab[s] = job.labels[P->lab_off[s]]; }
+    const int S = h.S, K = job.K, e0 = h.e0, Rn = h.e1 - h.e0, codeN = job.code_N;
+    for (int s = tid; s < S; s += blockDim.x) { s_slot[s] = P->sp[s].slot; s_lab[s] = job.labels[P->sp[s].lab_off]; }
     __syncthreads();
     for (int i = tid; i < S * KMAX; i += blockDim.x) {
         const int sx = i / KMAX, b = i % KMAX, a = s_lab[sx];
@@ -476,100 +508,27 @@ __global__ __launch_bounds__(256) void k_level_update(JobDev job, const LevelPar
     }
 }
 
-// after the update: the reads of the level are now present in read_loglik (`has`), and the draw slots
-// q = (entry, copy) of the level; the reference walks copies from cn down to 1 (:161-167)
-__global__ __launch_bounds__(256) void k_level_slots(JobDev job, const LevelParams* __restrict__ P, int do_update) {
-    const int e0 = P->e0, Rn = P->e1 - P->e0;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Rn; r += gridDim.x * blockDim.x) {
-        const int e = e0 + r;
-        const int rid = job.ent_rid[e], cn = job.ent_cn[e];
-        if (do_update) job.has[rid] = 1;
-        const int qb = job.ent_qoff[e];
-        const int mb = job.mate_ptr[rid], mn = job.mate_ptr[rid + 1] - mb;
-        const uint8_t code = (job.ent_lab_len[e] == 1) ? job.labels[job.ent_lab_off[e]] : (uint8_t)0xFF;
-        for (int i = 0; i < cn; i++) {
-            const int k = cn - 1 - i;
-            const int uid = (k < mn) ? job.mate_idx[mb + k] : -1;
-            job.qent[qb + i] = r;
-            job.quid[qb + i] = uid;
-            job.qcode[qb + i] = code;
-        }
+// The per-strain parameters of the level, straight from host-mapped memory into LDS: 16-byte loads over PCIe,
+// every thread a few, one round trip.
+__device__ __forceinline__ void stage_params(const LevelHdr& h, const LevelParams* __restrict__ P, StrainParam* s_sp, int* s_copy,
+                                             double* s_lpt, bool want_lpt, int tid, int nt) {
+    const i4v* src_sp = reinterpret_cast<const i4v*>(P->sp);
+    i4v* dst_sp = reinterpret_cast<i4v*>(s_sp);
+    for (int i = tid; i < h.S * 2; i += nt) dst_sp[i] = src_sp[i];
+    for (int i = tid; i < h.n_copy; i += nt) { s_copy[i] = P->copy_src[i]; s_copy[MAXS + i] = P->copy_dst[i]; }
+    if (want_lpt) {
+        const double2* s = reinterpret_cast<const double2*>(P->lpt);
+        double2* d = reinterpret_cast<double2*>(s_lpt);
+        for (int i = tid; i < h.S * (KK / 2); i += nt) d[i] = s[i];
     }
 }
 
-// MODE_SAMPLE: what the sampler draws from.  Per draw slot q: tabA[s][q] = ll(read) + ll(mate) (fp64, for
-// the checked tiers), qmax / qflag, and the fp32 weight row L[q][s] = exp(tabA - max_s) with the read's
-// symbol behind it (layout: chain_w_stride).  G lanes share a slot, each walks S / G strains; the max is
-// joined by shuffles.
-__host__ __device__ inline int chain_w_stride(int S) {
-    const int s4 = (S + 1 + 3) & ~3;                          // S weights + the read symbol
-    return (s4 & 4) ? s4 : s4 + 4;                            // 4 * odd: conflict-free 16-byte row reads
-}
-__global__ __launch_bounds__(256) void k_level_table(JobDev job, const LevelParams* __restrict__ P, int G) {
-    const int S = P->S, Q = P->Q, e0 = P->e0;
+// phase 0 inside the workgroup
+__device__ __forceinline__ void phase_copies(const JobDev& job, const LevelHdr& h, const int* s_copy, int tid, int nt) {
     const long stride = job.ll_stride;
-    const int wstride = chain_w_stride(S);
-    const int per = (S + G - 1) / G;                         // strains per lane
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int g = (int)(gid % G);
-    const long q = gid / G;
-    const bool live = q < Q;
-    const int s0 = g * per, s1 = (s0 + per < S) ? s0 + per : S;
-    double m = -INFINITY;
-    if (live) {
-        const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
-        const bool hr = job.has[rid] != 0, hu = uid >= 0 && job.has[uid] != 0;
-        for (int sx = s0; sx < s1; sx++) {
-            const double* row = job.ll + (long)P->slot[sx] * stride;
-            double x = hr ? row[rid] : 0.0;
-            if (hu) x += row[uid];
-            job.tabA[(long)sx * job.qcap + q] = x;
-            m = fmax(m, x);
-        }
-    }
-    for (int d = 1; d < G; d <<= 1) m = fmax(m, __shfl_xor(m, d));       // G is a power of two <= 16: lanes of one slot are adjacent
-    if (!live) return;
-    const bool flag = !(m >= -600.0);                        // underflow range of the reference's exp(); also NaN / -inf
-    float* Lf = job.tabLf + q * wstride;
-    for (int sx = s0; sx < s1; sx++) {
-        const double v = exp(job.tabA[(long)sx * job.qcap + q] - m);
-        Lf[sx] = flag ? __int_as_float(0x7fc00000) : (float)v;          // a NaN row sends the draw to the literal tier
-    }
-    if (g == 0) {
-        job.qflag[q] = flag ? 1 : 0;
-        job.qmax[q] = m;
-        // the read symbol rides behind the weights (a tiny denormal under a zero count: no effect on the sums)
-        const int c0 = job.qcode[q];
-        Lf[S] = __int_as_float(c0 < KMAX ? c0 : KMAX);
-        for (int sx = S + 1; sx < wstride; sx++) Lf[sx] = 0.0f;
-        // the chain reads whole 16-strain blocks: keep what follows the last row finite
-        if (q == Q - 1) for (int i = 0; i < 16; i++) Lf[wstride + i] = 0.0f;
-    }
-}
-
-// --------------------------------------------------------------------------
-// One level of the walk for one region.  Single workgroup.  `done` = LV_* pieces already run on the grid.
-__global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R,
-                                                int do_update, int done) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    double* s_a = reinterpret_cast<double*>(s_raw);              // [MAXS]
-    double* s_p = s_a + MAXS;                                    // [MAXS]
-    double* s_logpri = s_p + MAXS;                               // [MAXS]
-    unsigned* s_cnt = reinterpret_cast<unsigned*>(s_logpri + MAXS);   // [MAXS*KMAX]
-    int* s_slot = reinterpret_cast<int*>(s_cnt + MAXS * KMAX);   // [MAXS]
-    int* s_laboff = s_slot + MAXS;                               // [MAXS]
-    int* s_lablen = s_laboff + MAXS;                             // [MAXS]
-    unsigned char* s_big = s_raw + LDS_SMALL;                    // LDS_BIG bytes, reused per phase:
-    double* s_tab = reinterpret_cast<double*>(s_big);            //   [MAXS*KK] lpt, later the substitution histogram
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int S = P->S, K = job.K, e0 = P->e0, Rn = P->e1 - P->e0;
-    const long stride = job.ll_stride;
-    if (tid < S) { s_slot[tid] = P->slot[tid]; s_laboff[tid] = P->lab_off[tid]; s_lablen[tid] = P->lab_len[tid]; s_logpri[tid] = P->logpri[tid]; }
-
-    // ---- phase 0: rows of strains created by the last extension (Strain copy, Strain.cpp:73-83)
-    for (int c = 0; c < ((done & LV_COPIES_DONE) ? 0 : P->n_copy); c++) {
-        const double2* src = reinterpret_cast<const double2*>(job.ll + (long)P->copy_src[c] * stride);
-        double2* dst = reinterpret_cast<double2*>(job.ll + (long)P->copy_dst[c] * stride);
+    for (int c = 0; c < ((h.done & LV_COPIES_DONE) ? 0 : h.n_copy); c++) {
+        const double2* src = reinterpret_cast<const double2*>(job.ll + (long)s_copy[c] * stride);
+        double2* dst = reinterpret_cast<double2*>(job.ll + (long)s_copy[MAXS + c] * stride);
         const int n2 = (job.n_reads + 1) >> 1;
         int i = tid;
         for (; i + 3 * nt < n2; i += 4 * nt) {        // four independent 16-byte loads in flight per thread
@@ -579,113 +538,113 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
         for (; i < n2; i += nt) dst[i] = src[i];
         __syncthreads();                       // a later copy may read this row
     }
-    for (int i = tid; i < MAXS * KMAX; i += nt) s_cnt[i] = 0;
-    if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_pass = 0; R->chain_cycles = 0; R->chain_wall = 0; }
-    __syncthreads();
+}
 
-    // ---- phase 1: read log-likelihood update, NonparametricClustering.cpp:343-391
-    if (do_update && Rn > 0) {
-        for (int r = tid; r < Rn; r += nt) {
-            const int e = e0 + r;
-            job.isnew[r] = (job.ent_first[e] && !job.has[job.ent_rid[e]]) ? 1 : 0;
-        }
-        if (!(done & LV_ITEMS_DONE)) for (int i = tid; i < S * KK; i += nt) s_tab[i] = P->lpt[i];
-        __syncthreads();
-        const int codeN = job.code_N;
-        auto item = [&](int s, int r) {
-            const int e = e0 + r;
-            const int rid = job.ent_rid[e];
-            const uint8_t* sb = job.labels + s_laboff[s];
-            const uint8_t* rb = job.labels + job.ent_lab_off[e];
-            const int ls = s_lablen[s], lr = job.ent_lab_len[e];
-            const double* lp = s_tab + s * KK;
-            double val;
-            if (ls == 1) {
-                int a = sb[0], b = rb[0];
-                if (lr == 1) {
+// phase 1: read log-likelihood update, NonparametricClustering.cpp:343-391, then the reads of the level are
+// present in read_loglik (`has`).  s_lpt: the strains' log tables in LDS.
+__device__ __forceinline__ void phase_update(const JobDev& job, const LevelHdr& h, const StrainParam* s_sp, const double* s_lpt,
+                                             int tid, int nt) {
+    const int S = h.S, K = job.K, e0 = h.e0, Rn = h.e1 - h.e0;
+    const long stride = job.ll_stride;
+    for (int r = tid; r < Rn; r += nt) {
+        const int e = e0 + r;
+        job.isnew[r] = (job.ent_first[e] && !job.has[job.ent_rid[e]]) ? 1 : 0;
+    }
+    __syncthreads();
+    const int codeN = job.code_N;
+    auto item = [&](int s, int r) {
+        const int e = e0 + r;
+        const int rid = job.ent_rid[e];
+        const uint8_t* sb = job.labels + s_sp[s].lab_off;
+        const uint8_t* rb = job.labels + job.ent_lab_off[e];
+        const int ls = s_sp[s].lab_len, lr = job.ent_lab_len[e];
+        const double* lp = s_lpt + s * KK;
+        double val;
+        if (ls == 1) {
+            int a = sb[0], b = rb[0];
+            if (lr == 1) {
+                if (a == codeN) a = b;
+                val = (a < K && b < K) ? lp[a * KMAX + b] : __longlong_as_double(0x7ff8000000000000ll);
+            } else {
+                // logprob(sb, "multi"): sub_count[(sb, rb)] is created as 0 (std::map operator[]), so the
+                // result is log 0 - log comp(sb) = -inf for a symbol of the alphabet; for N (sb becomes rb)
+                // or a symbol outside the alphabet comp is created as 0 too: -inf - -inf
+                val = (a < 6 && a != codeN) ? -INFINITY : __longlong_as_double(0x7ff8000000000000ll);
+            }
+        } else {
+            val = 0.0;
+            if (job.isnew[r]) {
+                int ii = ls, jj = lr;
+                while (ii > 0 && jj > 0) {
+                    int a = sb[--ii], b = rb[--jj];
                     if (a == codeN) a = b;
-                    val = (a < K && b < K) ? lp[a * KMAX + b] : __longlong_as_double(0x7ff8000000000000ll);
-                } else {
-                    // logprob(sb, "multi"): sub_count[(sb, rb)] is created as 0 (std::map operator[]), so the
-                    // result is log 0 - log comp(sb) = -inf for a symbol of the alphabet; for N (sb becomes rb)
-                    // or a symbol outside the alphabet comp is created as 0 too: -inf - -inf
-                    val = (a < 6 && a != codeN) ? -INFINITY : __longlong_as_double(0x7ff8000000000000ll);
+                    val += lp[a * KMAX + b];
                 }
             } else {
-                val = 0.0;
-                if (job.isnew[r]) {
-                    int ii = ls, jj = lr;
-                    while (ii > 0 && jj > 0) {
-                        int a = sb[--ii], b = rb[--jj];
-                        if (a == codeN) a = b;
-                        val += lp[a * KMAX + b];
-                    }
-                } else {
-                    int ii = 0, jj = 0;
-                    while (ii < ls && jj < lr) {
-                        int a = sb[ii++], b = rb[jj++];
-                        if (a == codeN) a = b;
-                        val += lp[a * KMAX + b];
-                    }
-                }
-            }
-            double* cell = job.ll + (long)s_slot[s] * stride + rid;
-            const bool fresh = job.ent_first[e] && !job.has[rid];
-            *cell = fresh ? val : (*cell + val);            // Strain::update_read_loglik, Strain.cpp:85-95
-        };
-        if (done & LV_ITEMS_DONE) {
-            // k_level_update has applied the items
-        } else if (!P->has_dups && !P->any_multi) {
-            // single-symbol labels everywhere (the usual level): four items per thread in flight,
-            // so the dependent loads entry -> read id -> log-likelihood cell overlap
-            const long total = (long)S * Rn;
-            constexpr int U = 4;
-            for (long base = tid; base < total; base += (long)U * nt) {
-                int sidx[U], rid[U], bsym[U];
-                bool live[U], fresh[U];
-                double* cell[U];
-                double old[U];
-#pragma unroll
-                for (int k = 0; k < U; k++) {
-                    const long idx = base + (long)k * nt;
-                    live[k] = idx < total;
-                    const long ii = live[k] ? idx : 0;
-                    sidx[k] = (int)(ii / Rn);
-                    const int e = e0 + (int)(ii % Rn);
-                    rid[k] = job.ent_rid[e];
-                    bsym[k] = job.labels[job.ent_lab_off[e]];
-                    fresh[k] = job.ent_first[e] != 0;
-                }
-#pragma unroll
-                for (int k = 0; k < U; k++) {
-                    cell[k] = job.ll + (long)s_slot[sidx[k]] * stride + rid[k];
-                    fresh[k] = fresh[k] && !job.has[rid[k]];
-                    old[k] = *cell[k];
-                }
-#pragma unroll
-                for (int k = 0; k < U; k++) {
-                    int a = job.labels[s_laboff[sidx[k]]];
-                    const int b = bsym[k];
+                int ii = 0, jj = 0;
+                while (ii < ls && jj < lr) {
+                    int a = sb[ii++], b = rb[jj++];
                     if (a == codeN) a = b;
-                    const double val = (a < K && b < K) ? s_tab[sidx[k] * KK + a * KMAX + b] : __longlong_as_double(0x7ff8000000000000ll);
-                    if (live[k]) *cell[k] = fresh[k] ? val : (old[k] + val);       // Strain::update_read_loglik, Strain.cpp:85-95
+                    val += lp[a * KMAX + b];
                 }
             }
-        } else if (!P->has_dups) {
-            const long total = (long)S * Rn;
-            for (long idx = tid; idx < total; idx += nt) item((int)(idx / Rn), (int)(idx % Rn));
-        } else {
-            if (tid < S) for (int r = 0; r < Rn; r++) item(tid, r);
         }
-        __syncthreads();
-        for (int r = tid; r < Rn; r += nt) job.has[job.ent_rid[e0 + r]] = 1;
-        __syncthreads();
+        double* cell = job.ll + (long)s_sp[s].slot * stride + rid;
+        const bool fresh = job.ent_first[e] && !job.has[rid];
+        *cell = fresh ? val : (*cell + val);            // Strain::update_read_loglik, Strain.cpp:85-95
+    };
+    if (h.done & LV_ITEMS_DONE) {
+        // k_level_update has applied the items
+    } else if (!h.has_dups && !h.any_multi) {
+        // single-symbol labels everywhere (the usual level): four items per thread in flight,
+        // so the dependent loads entry -> read id -> log-likelihood cell overlap
+        const long total = (long)S * Rn;
+        constexpr int U = 4;
+        for (long base = tid; base < total; base += (long)U * nt) {
+            int sidx[U], rid[U], bsym[U];
+            bool live[U], fresh[U];
+            double* cell[U];
+            double old[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const long idx = base + (long)k * nt;
+                live[k] = idx < total;
+                const long ii = live[k] ? idx : 0;
+                sidx[k] = (int)(ii / Rn);
+                const int e = e0 + (int)(ii % Rn);
+                rid[k] = job.ent_rid[e];
+                bsym[k] = job.labels[job.ent_lab_off[e]];
+                fresh[k] = job.ent_first[e] != 0;
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                cell[k] = job.ll + (long)s_sp[sidx[k]].slot * stride + rid[k];
+                fresh[k] = fresh[k] && !job.has[rid[k]];
+                old[k] = *cell[k];
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                int a = job.labels[s_sp[sidx[k]].lab_off];
+                const int b = bsym[k];
+                if (a == codeN) a = b;
+                const double val = (a < K && b < K) ? s_lpt[sidx[k] * KK + a * KMAX + b] : __longlong_as_double(0x7ff8000000000000ll);
+                if (live[k]) *cell[k] = fresh[k] ? val : (old[k] + val);       // Strain::update_read_loglik, Strain.cpp:85-95
+            }
+        }
+    } else if (!h.has_dups) {
+        const long total = (long)S * Rn;
+        for (long idx = tid; idx < total; idx += nt) item((int)(idx / Rn), (int)(idx % Rn));
+    } else {
+        if (tid < S) for (int r = 0; r < Rn; r++) item(tid, r);
     }
-    if (Rn <= 0 || S <= 0) return;
+    __syncthreads();
+    for (int r = tid; r < Rn; r += nt) job.has[job.ent_rid[e0 + r]] = 1;
+    __syncthreads();
+}
 
-    // ---- phase 2: draw slots q = (entry, copy); the reference walks copies from cn down to 1
-    const int Q = P->Q;
-    const int mode = P->mode;
+// phase 2: draw slots q = (entry, copy); the reference walks copies from cn down to 1 (:161-167)
+__device__ __forceinline__ void phase_slots(const JobDev& job, const LevelHdr& h, int tid, int nt) {
+    const int e0 = h.e0, Rn = h.e1 - h.e0;
     for (int r = tid; r < Rn; r += nt) {
         const int e = e0 + r;
         const int rid = job.ent_rid[e], cn = job.ent_cn[e];
@@ -701,155 +660,251 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, const LevelParams* __
         }
     }
     __syncthreads();
+}
 
-    if (mode == MODE_HARD) {
-        // hard_clustering, NonparametricClustering.cpp:17-125
-        // logprob(uid) inserts a zero log-likelihood for a mate not seen yet (Strain.cpp:147-150)
-        for (int q = tid; q < Q; q += nt) {
-            const int uid = job.quid[q];
-            if (uid >= 0 && !job.has[uid])
-                for (int s = 0; s < S; s++) job.ll[(long)s_slot[s] * stride + uid] = 0.0;
-        }
-        __syncthreads();
-        for (int q = tid; q < Q; q += nt) { const int uid = job.quid[q]; if (uid >= 0) job.has[uid] = 1; }
-        __syncthreads();
-        for (int q = tid; q < Q; q += nt) {
-            const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
-            // p_s = exp(x_s) / sum_s exp(x_s) (:186-192).  The reference forms it in long double, where
-            // exp(-800) is an ordinary number (a read laid against a long collapsed node it does not match
-            // reaches such log-likelihoods for every strain); in fp64 the same quotient needs the maximum
-            // taken out first.  A NaN x_s still makes every p NaN, as in the reference.
-            double m = -INFINITY;
-            for (int s = 0; s < S; s++) {
-                const double* row = job.ll + (long)s_slot[s] * stride;
-                double x = s_logpri[s] + row[rid];
-                if (uid >= 0) x += row[uid];
-                job.tabA[(long)s * job.qcap + q] = x;
-                m = fmax(m, x);
-            }
-            double norm = 0;
-            for (int s = 0; s < S; s++) {
-                const double p = exp(job.tabA[(long)s * job.qcap + q] - m);
-                job.tabA[(long)s * job.qcap + q] = p;
-                norm += p;
-            }
-            for (int s = 0; s < S; s++) job.tabA[(long)s * job.qcap + q] /= norm;
-        }
-        for (int i = tid; i < S * KK; i += nt) s_tab[i] = 0.0;
-        __syncthreads();
-        if (!P->any_multi) {
-            // thread (s, b): responsibilities summed in draw-slot order, as the reference adds them
-            for (int idx = tid; idx < S * (K + 1); idx += nt) {
-                const int s = idx / (K + 1), b = idx % (K + 1);
-                const double* prow = job.tabA + (long)s * job.qcap;
-                double acc = 0;
-                if (b == K) {
-#pragma unroll 8
-                    for (int q = 0; q < Q; q++) acc += prow[q];
-                    R->abund[s] = acc;
-                } else {
-#pragma unroll 8
-                    for (int q = 0; q < Q; q++) acc += (job.qcode[q] == b) ? prow[q] : 0.0;
-                    const int a = job.labels[s_laboff[s]];
-                    s_tab[s * KK + a * KMAX + b] = acc;
-                }
-            }
-        } else {
-            if (tid < S) {
-                const int s = tid;
-                const double* prow = job.tabA + (long)s * job.qcap;
-                double* hist = s_tab + s * KK;
-                const uint8_t* sb = job.labels + s_laboff[s];
-                const int ls = s_lablen[s];
-                double acc = 0;
-                for (int q = 0; q < Q; q++) {
-                    const double p = prow[q];
-                    acc += p;
-                    const int r = job.qent[q], e = e0 + r;
-                    const uint8_t* rb = job.labels + job.ent_lab_off[e];
-                    const int lr = job.ent_lab_len[e];
-                    if (lr == 1) {
-                        if (ls == 1) hist[sb[0] * KMAX + rb[0]] += p;
-                    } else if (job.isnew[r]) {
-                        int i = ls, j = lr;
-                        while (i > 0 && j > 0) { int a = sb[--i], b = rb[--j]; hist[a * KMAX + b] += p; }
-                    } else {
-                        int i = 0, j = 0;
-                        while (i < ls && j < lr) { int a = sb[i++], b = rb[j++]; hist[a * KMAX + b] += p; }
-                    }
-                }
-                R->abund[s] = acc;
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < S * KK; i += nt) R->subst[i] = s_tab[i];
-        return;
+// every result of the level is in host memory before the stamp
+__device__ __forceinline__ void finish_level(const LevelHdr& h, LevelResult* __restrict__ R, unsigned long long wall0, int tid) {
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        R->level_wall = wall_clock64() - wall0;
+        R->xcc = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xF);      // HW_REG_XCC_ID[3:0]
+        __hip_atomic_store(&R->seq, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
 
-    // MODE_SAMPLE: k_level_table builds what the sampler draws from
+__host__ __device__ inline int chain_w_stride(int S) {
+    const int s4 = (S + 1 + 3) & ~3;                          // S weights + the read symbol
+    return (s4 & 4) ? s4 : s4 + 4;                            // 4 * odd: conflict-free 16-byte row reads
+}
+
+// LDS of the level kernels: per-strain scalars first, then one big region that holds the strains' log tables
+// during the update and the sampler's uniforms + weight rows (or the soft update's histogram) afterwards.
+struct LevelLds {
+    double* s_a; double* s_p; unsigned* s_cnt; int* s_slot; unsigned* s_kf; float* s_a0f; int* s_x; int* s_copy;
+    StrainParam* s_sp; unsigned char* s_big;
+};
+__device__ __forceinline__ LevelLds level_lds(unsigned char* raw) {
+    LevelLds l;
+    l.s_a = reinterpret_cast<double*>(raw);                        // [MAXS]
+    l.s_p = l.s_a + MAXS;                                          // [MAXS]
+    l.s_sp = reinterpret_cast<StrainParam*>(l.s_p + MAXS);         // [MAXS]
+    l.s_cnt = reinterpret_cast<unsigned*>(l.s_sp + MAXS);          // [MAXS*KMAX]
+    l.s_slot = reinterpret_cast<int*>(l.s_cnt + MAXS * KMAX);      // [MAXS]
+    l.s_kf = reinterpret_cast<unsigned*>(l.s_slot + MAXS);         // [MAXS] draws per strain so far
+    l.s_a0f = reinterpret_cast<float*>(l.s_kf + MAXS);             // [MAXS] fp32 copy of the starting weights
+    l.s_copy = reinterpret_cast<int*>(l.s_a0f + MAXS);             // [2*MAXS]
+    l.s_x = l.s_copy + 2 * MAXS;                                   // [8] first failing position per wave
+    l.s_big = raw + LDS_SMALL;
+    return l;
 }
 
 // --------------------------------------------------------------------------
-// a14 / a18: the urn sampler of one level, np_bayes_clustering
-// (NonparametricClustering.cpp:128-244) and read_assign (:776-836).  One
-// workgroup: the fp32 weight rows L[q][s] = exp(ll - max_s ll) built by
-// k_level_table move into LDS when they fit (else they are read from HBM/L2),
-// then four or eight wavefronts run the chain (urn_chain_q).  NB = ceil(S / 16):
-// every lane of a quad owns 4 * NB consecutive strains.
+// a13 + a14 / a18: one sampler level in ONE launch -- np_bayes_clustering
+// (NonparametricClustering.cpp:128-244) on the level's reads, and read_assign
+// (:776-836) on the pseudo-level of all reads.  One workgroup: the per-strain
+// parameters arrive from host-mapped memory, new strains get their rows, the
+// level's read log-likelihoods are updated (a13), the draw slots and the fp32
+// weight rows L[q][s] = exp(ll - max_s ll) are built straight into LDS (HBM when
+// they do not fit), then four or eight wavefronts run the urn chain
+// (urn_chain_q) and the results go to host-mapped memory, stamped.
+// NB = ceil(S / 16): every lane of a quad owns 4 * NB consecutive strains.
 constexpr int CHAINW_ROWS_BYTES = LDS_BIG - UWIN * 4;
-constexpr int CHAIN_THREADS = 512;   // eight wavefronts build the weight rows
+constexpr int CHAIN_THREADS = 512;   // eight wavefronts build the level
 // wavefronts that run the chain = window of 16 * NW draws: all eight while a lane's share of the strains is
 // small (the pass is latency-bound and a wider window accepts more draws), four otherwise (the others leave)
 constexpr int chain_nw(int nb) { return nb <= 2 ? 8 : 4; }
 template <int NB, bool ROWS_LDS>
-__global__ __launch_bounds__(CHAIN_THREADS) void k_chain_w(JobDev job, const LevelParams* __restrict__ P, LevelResult* __restrict__ R) {
+__global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(JobDev job, LevelHdr h, const LevelParams* __restrict__ P,
+                                                                LevelResult* __restrict__ R) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    double* s_a = reinterpret_cast<double*>(s_raw);              // [MAXS]
-    double* s_p = s_a + MAXS;                                    // [MAXS]
-    unsigned* s_cnt = reinterpret_cast<unsigned*>(s_p + MAXS);   // [MAXS*KMAX]
-    int* s_slot = reinterpret_cast<int*>(s_cnt + MAXS * KMAX);   // [MAXS]
-    unsigned* s_kf = reinterpret_cast<unsigned*>(s_slot + MAXS); // [MAXS] draws per strain so far
-    float* s_a0f = reinterpret_cast<float*>(s_kf + MAXS);                                  // [MAXS] fp32 copy of the starting weights
-    int* s_x = reinterpret_cast<int*>(s_a0f + MAXS);             // [8] first failing position per wave
-    float* s_uwin = reinterpret_cast<float*>(s_raw + LDS_SMALL); // [UWIN]
+    const unsigned long long wall0 = wall_clock64();
+    const LevelLds l = level_lds(s_raw);
+    float* s_uwin = reinterpret_cast<float*>(l.s_big);           // [UWIN]
     float* s_rows = s_uwin + UWIN;
     const int tid = threadIdx.x;
     int nt = blockDim.x;
-    const int S = P->S, Q = P->Q;
+    const int S = h.S, Q = h.Q, e0 = h.e0, Rn = h.e1 - h.e0;
     const int stride = chain_w_stride(S);
-    for (int i = tid; i < MAXS * KMAX; i += nt) s_cnt[i] = 0;
-    if (tid < MAXS) {
-        s_slot[tid] = tid < S ? P->slot[tid] : 0;
-        s_kf[tid] = 0u;
-        s_a0f[tid] = tid < S ? (float)P->a0[tid] : 0.0f;
-    }
+    const bool upd = h.do_update && Rn > 0;
+    stage_params(h, P, l.s_sp, l.s_copy, reinterpret_cast<double*>(l.s_big), upd && !(h.done & LV_ITEMS_DONE), tid, nt);
+    for (int i = tid; i < MAXS * KMAX; i += nt) l.s_cnt[i] = 0;
     if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_pass = 0; R->chain_cycles = 0; R->chain_wall = 0; }
-    if (ROWS_LDS) {
-        // the weight rows (built by k_level_table) move into LDS
-        const int n4 = (Q * stride + 16) / 4;                 // stride is a multiple of 4
-        const f4v* src = reinterpret_cast<const f4v*>(job.tabLf);
-        f4v* dst = reinterpret_cast<f4v*>(s_rows);
-        for (int i = tid; i < n4; i += nt) dst[i] = src[i];
+    __syncthreads();
+    if (tid < MAXS) {
+        l.s_slot[tid] = tid < S ? l.s_sp[tid].slot : 0;
+        l.s_kf[tid] = 0u;
+        l.s_a0f[tid] = tid < S ? (float)l.s_sp[tid].a0 : 0.0f;
+    }
+    phase_copies(job, h, l.s_copy, tid, nt);
+    if (upd) phase_update(job, h, l.s_sp, reinterpret_cast<const double*>(l.s_big), tid, nt);
+    phase_slots(job, h, tid, nt);
+
+    // what the sampler draws from.  Per draw slot q the fp32 weight row L[q][s] = exp(x_s - max_s x_s),
+    // x_s = ll(read) + ll(mate) in fp64, with the read's symbol behind it.  G lanes share a slot, each walks
+    // <= 8 strains; the max is joined by shuffles.  A slot whose log-likelihoods lie in the underflow range of
+    // the reference's exp() gets a NaN row, which sends its draws to the checked tiers.
+    {
+        int G = 1;
+        while (G < 16 && G * 8 < S) G <<= 1;
+        const int per = (S + G - 1) / G;                     // <= 8 strains per lane
+        const long lstride = job.ll_stride;
+        SC_GLOBAL float* rows_g = (SC_GLOBAL float*)job.tabLf;
+        auto put = [&](long idx, float v) __attribute__((always_inline)) { if (ROWS_LDS) s_rows[idx] = v; else rows_g[idx] = v; };
+        for (long gid = tid; gid < (long)Q * G; gid += nt) {
+            const int g = (int)(gid % G);
+            const long q = gid / G;
+            const int s0 = g * per, s1 = (s0 + per < S) ? s0 + per : S;
+            const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
+            const bool hr = job.has[rid] != 0, hu = uid >= 0 && job.has[uid] != 0;
+            double x[8], m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int sx = s0 + i;
+                x[i] = -INFINITY;
+                if (sx < s1) {
+                    const double* row = job.ll + (long)l.s_slot[sx] * lstride;
+                    double v = hr ? row[rid] : 0.0;
+                    if (hu) v += row[uid];
+                    x[i] = v;
+                    m = fmax(m, v);
+                }
+            }
+            for (int d = 1; d < G; d <<= 1) m = fmax(m, __shfl_xor(m, d));       // G is a power of two <= 16: lanes of one slot are adjacent
+            const bool flag = !(m >= -600.0);                // underflow range of the reference's exp(); also NaN / -inf
+            const long Lf = q * stride;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int sx = s0 + i;
+                if (sx < s1) put(Lf + sx, flag ? __int_as_float(0x7fc00000) : (float)exp(x[i] - m));
+            }
+            if (g == 0) {
+                // the read symbol rides behind the weights (a tiny denormal under a zero count: no effect on the sums)
+                const int c0 = job.qcode[q];
+                put(Lf + S, __int_as_float(c0 < KMAX ? c0 : KMAX));
+                for (int sx = S + 1; sx < stride; sx++) put(Lf + sx, 0.0f);
+                // the chain reads whole 16-strain blocks: keep what follows the last row finite
+                if (q == Q - 1) for (int i = 0; i < 16; i++) put(Lf + stride + i, 0.0f);
+            }
+        }
     }
     __syncthreads();
     constexpr int NW = chain_nw(NB);
     if (tid >= 64 * NW) return;                            // a finished wavefront no longer counts at the barriers below
     nt = 64 * NW;
-    const int total = P->n_sweeps * Q;
-    if (S < 2) {
-        // a single candidate takes every draw (discrete_distribution with one weight)
-        for (int t = tid; t < total; t += nt) {
-            const int code = job.qcode[t % Q];
-            if (code < KMAX) atomicAdd(&s_cnt[code], 1u);
-        }
-        if (tid == 0) { R->abund[0] = P->a0[0] + (double)total; R->kdraw[0] = (unsigned)total; R->n_draws = (unsigned long long)total; }
-    } else {
-        urn_chain_q<NB, ROWS_LDS, NW>(job, P, R, s_slot, s_a, s_p, s_kf, s_a0f, s_cnt, s_x, s_uwin, s_rows, stride, tid);
-    }
+    urn_chain_q<NB, ROWS_LDS, NW>(job, h, l.s_sp, R, l.s_slot, l.s_a, l.s_p, l.s_kf, l.s_a0f, l.s_cnt, l.s_x, s_uwin, s_rows, stride, tid);
     __syncthreads();
-    for (int i = tid; i < S * KMAX; i += nt) R->cnt[i] = s_cnt[i];
+    for (int i = tid; i < S * KMAX; i += nt) R->cnt[i] = l.s_cnt[i];
+    finish_level(h, R, wall0, tid);
 }
 
+// --------------------------------------------------------------------------
+// a13 + a15: one level without the sampler in one launch -- the read log-likelihood update, and for MODE_HARD
+// the soft update hard_clustering (NonparametricClustering.cpp:17-125).  Single workgroup.
+__global__ __launch_bounds__(512) void k_level(JobDev job, LevelHdr h, const LevelParams* __restrict__ P, LevelResult* __restrict__ R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const unsigned long long wall0 = wall_clock64();
+    const LevelLds l = level_lds(s_raw);
+    double* s_tab = reinterpret_cast<double*>(l.s_big);          //   [MAXS*KK] lpt, later the substitution histogram
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int S = h.S, K = job.K, e0 = h.e0, Rn = h.e1 - h.e0;
+    const long stride = job.ll_stride;
+    const bool upd = h.do_update && Rn > 0;
+    stage_params(h, P, l.s_sp, l.s_copy, s_tab, upd && !(h.done & LV_ITEMS_DONE), tid, nt);
+    if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_pass = 0; R->chain_cycles = 0; R->chain_wall = 0; }
+    __syncthreads();
+    phase_copies(job, h, l.s_copy, tid, nt);
+    if (upd) phase_update(job, h, l.s_sp, s_tab, tid, nt);
+    if (Rn <= 0 || S <= 0 || h.mode != MODE_HARD) { finish_level(h, R, wall0, tid); return; }
+    phase_slots(job, h, tid, nt);
+
+    // hard_clustering, NonparametricClustering.cpp:17-125
+    const int Q = h.Q;
+    // logprob(uid) inserts a zero log-likelihood for a mate not seen yet (Strain.cpp:147-150)
+    for (int q = tid; q < Q; q += nt) {
+        const int uid = job.quid[q];
+        if (uid >= 0 && !job.has[uid])
+            for (int s = 0; s < S; s++) job.ll[(long)l.s_sp[s].slot * stride + uid] = 0.0;
+    }
+    __syncthreads();
+    for (int q = tid; q < Q; q += nt) { const int uid = job.quid[q]; if (uid >= 0) job.has[uid] = 1; }
+    __syncthreads();
+    // x[s][q] = log prior + ll(read) + ll(mate): one (strain, slot) pair per thread and step, so the scattered
+    // row reads of a slot's strains are all in flight together
+    for (long idx = tid; idx < (long)S * Q; idx += nt) {
+        const int s = (int)(idx / Q), q = (int)(idx % Q);
+        const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
+        const double* row = job.ll + (long)l.s_sp[s].slot * stride;
+        double x = l.s_sp[s].logpri + row[rid];
+        if (uid >= 0) x += row[uid];
+        job.tabA[(long)s * job.qcap + q] = x;
+    }
+    __syncthreads();
+    for (int q = tid; q < Q; q += nt) {
+        // p_s = exp(x_s) / sum_s exp(x_s) (:186-192).  The reference forms it in long double, where
+        // exp(-800) is an ordinary number (a read laid against a long collapsed node it does not match
+        // reaches such log-likelihoods for every strain); in fp64 the same quotient needs the maximum
+        // taken out first.  A NaN x_s still makes every p NaN, as in the reference.
+        const double* col = job.tabA + q;
+        double m = -INFINITY;
+        for (int s = 0; s < S; s++) m = fmax(m, col[(long)s * job.qcap]);
+        double norm = 0;
+        for (int s = 0; s < S; s++) norm += exp(col[(long)s * job.qcap] - m);
+        for (int s = 0; s < S; s++) {
+            double* cell = job.tabA + (long)s * job.qcap + q;
+            *cell = exp(*cell - m) / norm;
+        }
+    }
+    for (int i = tid; i < S * KK; i += nt) s_tab[i] = 0.0;
+    __syncthreads();
+    if (!h.any_multi) {
+        // thread (s, b): responsibilities summed in draw-slot order, as the reference adds them
+        for (int idx = tid; idx < S * (K + 1); idx += nt) {
+            const int s = idx / (K + 1), b = idx % (K + 1);
+            const double* prow = job.tabA + (long)s * job.qcap;
+            double acc = 0;
+            if (b == K) {
+#pragma unroll 8
+                for (int q = 0; q < Q; q++) acc += prow[q];
+                R->abund[s] = acc;
+            } else {
+#pragma unroll 8
+                for (int q = 0; q < Q; q++) acc += (job.qcode[q] == b) ? prow[q] : 0.0;
+                const int a = job.labels[l.s_sp[s].lab_off];
+                s_tab[s * KK + a * KMAX + b] = acc;
+            }
+        }
+    } else {
+        if (tid < S) {
+            const int s = tid;
+            const double* prow = job.tabA + (long)s * job.qcap;
+            double* hist = s_tab + s * KK;
+            const uint8_t* sb = job.labels + l.s_sp[s].lab_off;
+            const int ls = l.s_sp[s].lab_len;
+            double acc = 0;
+            for (int q = 0; q < Q; q++) {
+                const double p = prow[q];
+                acc += p;
+                const int r = job.qent[q], e = e0 + r;
+                const uint8_t* rb = job.labels + job.ent_lab_off[e];
+                const int lr = job.ent_lab_len[e];
+                if (lr == 1) {
+                    if (ls == 1) hist[sb[0] * KMAX + rb[0]] += p;
+                } else if (job.isnew[r]) {
+                    int i = ls, j = lr;
+                    while (i > 0 && j > 0) { int a = sb[--i], b = rb[--j]; hist[a * KMAX + b] += p; }
+                } else {
+                    int i = 0, j = 0;
+                    while (i < ls && j < lr) { int a = sb[i++], b = rb[j++]; hist[a * KMAX + b] += p; }
+                }
+            }
+            R->abund[s] = acc;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < S * KK; i += nt) R->subst[i] = s_tab[i];
+    finish_level(h, R, wall0, tid);
+}
 // --------------------------------------------------------------------------
 // a7/a8: progressive sum-of-pairs MSA, MultipleSequenceAlignmentSP.cpp:10-301,
 // scored with SimpleDnaScore (SimpleDnaScore.cpp:15-42, Score.hpp:35).
@@ -1163,67 +1218,68 @@ void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node
 }
 constexpr size_t LEVEL_LDS = LDS_SMALL + sizeof(double) * MAXS * KK;
 constexpr size_t CHAIN_LDS = LDS_TOTAL;
-template <int NB, bool L> static int set_chain_w_attr() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_w<NB, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
+template <int NB, bool L> static int set_sample_attr() {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level_sample<NB, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
 }
 int init_kernels() {
     int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEVEL_LDS);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msa<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSA_LDS);
-    rc |= set_chain_w_attr<1, true>(); rc |= set_chain_w_attr<1, false>();
-    rc |= set_chain_w_attr<2, true>(); rc |= set_chain_w_attr<2, false>();
-    rc |= set_chain_w_attr<3, true>(); rc |= set_chain_w_attr<3, false>();
-    rc |= set_chain_w_attr<4, true>(); rc |= set_chain_w_attr<4, false>();
-    rc |= set_chain_w_attr<5, true>(); rc |= set_chain_w_attr<5, false>();
-    rc |= set_chain_w_attr<6, true>(); rc |= set_chain_w_attr<6, false>();
-    rc |= set_chain_w_attr<7, true>(); rc |= set_chain_w_attr<7, false>();
-    rc |= set_chain_w_attr<8, true>(); rc |= set_chain_w_attr<8, false>();
+    rc |= set_sample_attr<1, true>(); rc |= set_sample_attr<1, false>();
+    rc |= set_sample_attr<2, true>(); rc |= set_sample_attr<2, false>();
+    rc |= set_sample_attr<3, true>(); rc |= set_sample_attr<3, false>();
+    rc |= set_sample_attr<4, true>(); rc |= set_sample_attr<4, false>();
+    rc |= set_sample_attr<5, true>(); rc |= set_sample_attr<5, false>();
+    rc |= set_sample_attr<6, true>(); rc |= set_sample_attr<6, false>();
+    rc |= set_sample_attr<7, true>(); rc |= set_sample_attr<7, false>();
+    rc |= set_sample_attr<8, true>(); rc |= set_sample_attr<8, false>();
     return rc;
 }
-// One level: the data-parallel pieces on a grid when the level has the usual shape, the rest in k_level.
-void launch_level(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, const LevelParams& H, int do_update) {
-    const int S = H.S, Rn = H.e1 - H.e0;
+// A level of ordinary size is ONE launch (launch_level).  Only when a level has so many (strain, read) items or
+// such long rows that a single workgroup would crawl (unthinned deep coverage) do the row copies and the
+// single-symbol update run on a grid first; `Pd` is then a device copy of the parameters the caller has put
+// in front of these launches on the same stream.  Returns the LV_* bits to pass on in LevelHdr::done.
+constexpr long GRID_ITEMS = 1L << 17;          // (strain, read) items of a level
+constexpr long GRID_COPY_WORDS = 1L << 19;     // doubles copied for new strains
+bool level_wants_grid(const JobDev& job, const LevelHdr& h) {
+    const long items = (long)h.S * (h.e1 - h.e0);
+    return (h.do_update && items > GRID_ITEMS && !h.has_dups && !h.any_multi) || (long)h.n_copy * job.n_reads > GRID_COPY_WORDS;
+}
+int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* Pd) {
+    const int S = h.S, Rn = h.e1 - h.e0;
     int done = 0;
-    if (H.n_copy > 0) {
+    if ((long)h.n_copy * job.n_reads > GRID_COPY_WORDS) {
         const int n2 = (job.n_reads + 1) >> 1;
         int bx = (n2 + 1023) / 1024;
-        bx = bx < 1 ? 1 : (bx > 32 ? 32 : bx);
-        hipLaunchKernelGGL(k_level_copy, dim3(bx, H.n_copy), dim3(256), 0, st, job, P);
+        bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
+        hipLaunchKernelGGL(k_level_copy, dim3(bx, h.n_copy), dim3(256), 0, st, job, Pd);
         done |= LV_COPIES_DONE;
     }
-    if (do_update && Rn > 0 && S > 0 && !H.has_dups && !H.any_multi) {
-        const long items = (long)S * Rn;
+    const long items = (long)S * Rn;
+    if (h.do_update && items > GRID_ITEMS && !h.has_dups && !h.any_multi) {
         int g = (int)((items + 511) / 512);
-        g = g < 1 ? 1 : (g > 128 ? 128 : g);
-        hipLaunchKernelGGL(k_level_update, dim3(g), dim3(256), 0, st, job, P);
+        g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+        hipLaunchKernelGGL(k_level_update, dim3(g), dim3(256), 0, st, job, h, Pd);
         done |= LV_ITEMS_DONE;
     }
-    const bool table = H.mode == MODE_SAMPLE && H.n_sweeps > 0 && S > 1 && Rn > 0;
-    if (table && (!do_update || (done & LV_ITEMS_DONE))) {
-        // a sampler level of the usual shape: nothing order-dependent is left for k_level
-        int g = (Rn + 255) / 256;
-        g = g > 64 ? 64 : g;
-        hipLaunchKernelGGL(k_level_slots, dim3(g), dim3(256), 0, st, job, P, do_update);
-    } else {
-        hipLaunchKernelGGL(k_level, dim3(1), dim3(512), LEVEL_LDS, st, job, P, R, do_update, done);
-    }
-    if (table) {
-        int G = 1;
-        while (G < 16 && G * 8 < S) G <<= 1;                  // <= 8 strains per lane
-        const long threads = (long)H.Q * G;
-        hipLaunchKernelGGL(k_level_table, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, job, P, G);
-    }
+    return done;
 }
-// S, Q of the level decide the chain variant and whether the fp32 rows fit in LDS.
-void launch_chain(hipStream_t st, const JobDev& job, const LevelParams* P, LevelResult* R, int S, int Q) {
-    const bool wl = ((long)Q * chain_w_stride(S) + 16) * 4 <= (long)CHAINW_ROWS_BYTES;
-#define SC_CHAINW(NB) case NB: if (wl) hipLaunchKernelGGL((k_chain_w<NB, true>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, P, R); \
-                               else hipLaunchKernelGGL((k_chain_w<NB, false>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, P, R); break;
-    switch ((S + 15) / 16) {
-        SC_CHAINW(1) SC_CHAINW(2) SC_CHAINW(3) SC_CHAINW(4) SC_CHAINW(5) SC_CHAINW(6) SC_CHAINW(7)
-        default: if (wl) hipLaunchKernelGGL((k_chain_w<8, true>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, P, R);
-                 else hipLaunchKernelGGL((k_chain_w<8, false>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, P, R);
+// One level = one launch: S, Q of the level decide the sampler variant and whether the fp32 rows fit in LDS.
+void launch_level(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* P, LevelResult* R) {
+    const int S = h.S, Q = h.Q, Rn = h.e1 - h.e0;
+    const bool chain = h.mode == MODE_SAMPLE && h.n_sweeps > 0 && S > 1 && Rn > 0;
+    if (!chain) {
+        hipLaunchKernelGGL(k_level, dim3(1), dim3(512), LEVEL_LDS, st, job, h, P, R);
+        return;
     }
-#undef SC_CHAINW
+    const bool wl = ((long)Q * chain_w_stride(S) + 16) * 4 <= (long)CHAINW_ROWS_BYTES;
+#define SC_SAMPLE(NB) case NB: if (wl) hipLaunchKernelGGL((k_level_sample<NB, true>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, h, P, R); \
+                               else hipLaunchKernelGGL((k_level_sample<NB, false>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, h, P, R); break;
+    switch ((S + 15) / 16) {
+        SC_SAMPLE(1) SC_SAMPLE(2) SC_SAMPLE(3) SC_SAMPLE(4) SC_SAMPLE(5) SC_SAMPLE(6) SC_SAMPLE(7)
+        default: if (wl) hipLaunchKernelGGL((k_level_sample<8, true>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, h, P, R);
+                 else hipLaunchKernelGGL((k_level_sample<8, false>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, h, P, R);
+    }
+#undef SC_SAMPLE
 }
 void launch_msa(hipStream_t st, const MsaDev& d) {
     if (d.cmax > MSA_CM) hipLaunchKernelGGL(k_msa<true>, dim3(1), dim3(256), 0, st, d);      // state in HBM scratch

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Where does the time go with R regions in flight on one GPU?  For each R: wall time of R regions of the
+configs[1] shape (seeds 21..), and per region the host-side level-walk time against the time spent INSIDE
+the level kernels (sc_stats.level_kernel_ticks, 100 MHz ticks from kernel start to completion stamp) and
+inside the urn chains.  usage: python3 tools/inflight_probe.py [R ...]   (env SC_PROBE_READS, SC_PROBE_PROCS)"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def prepare(n, reads):
+    from rambl_amd import cli, stage5, synth
+    d = tempfile.mkdtemp(prefix="probe_")
+    out = []
+    for k in range(n):
+        g = synth.make_gene(21 + k, glen=1500, n_strains=3, n_reads=reads, name="gene%d" % (21 + k))
+        fa, sam = synth.write_dataset(os.path.join(d, "r%d" % k), [g])
+        pa = cli.parse_cmd_line(stage5.straincall_argv("%s:1-1500" % g["name"], fa, sam))
+        out.append((pa, cli.load_regions(pa)))
+    return out
+
+
+def multi(procs, r):
+    """`procs` processes with r regions in flight each, started together (children wait for a common time)."""
+    import subprocess
+    t_start = time.time() + float(os.environ.get("SC_PROBE_LEAD", "45"))
+    env = dict(os.environ, SC_PROBE_START=repr(t_start), SC_PROBE_PROCS="1")
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r)], env=env, stdout=subprocess.PIPE) for _ in range(procs)]
+    outs = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in ps]
+    t_end = max(o["t_end"] for o in outs)
+    reads = int(os.environ.get("SC_PROBE_READS", "10000"))
+    print(json.dumps(dict(procs=procs, regions_per_proc=r, seconds=round(t_end - t_start, 3),
+                          reads_per_s=round(procs * r * reads / (t_end - t_start)),
+                          level_kernel_ms=[o["level_kernel_ms"] for o in outs], cluster_ms=[o["cluster_ms"] for o in outs])), flush=True)
+
+
+def main():
+    procs = int(os.environ.get("SC_PROBE_PROCS", "1"))
+    if procs > 1:
+        for r in [int(x) for x in sys.argv[1:]]:
+            multi(procs, r)
+        return
+    rs = [int(x) for x in sys.argv[1:]] or [1, 4, 16, 32]
+    reads = int(os.environ.get("SC_PROBE_READS", "10000"))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("SC_PROBE_QUEUES", "24"))
+    from rambl_amd import capi, stage5
+    prep = prepare(max(rs), reads)
+    for r in rs:
+        ctx = capi.Context(0, r)
+        params = capi.default_params(0.01, 0.02, 0.02)
+        stage5.run_regions(ctx, prep[:min(r, 4)], r, params)        # warm
+        if os.environ.get("SC_PROBE_START"):
+            while time.time() < float(os.environ["SC_PROBE_START"]):
+                time.sleep(0.0005)
+        t0 = time.time()
+        _, stats = stage5.run_regions(ctx, prep[:r], r, params)
+        t_end = time.time()
+        dt = t_end - t0
+        ctx.close()
+        n = len(stats)
+        rec = dict(regions=r, seconds=round(dt, 3), reads_per_s=round(r * reads / dt),
+                   cluster_ms=round(sum(s["cluster_ms"] for s in stats) / n, 1),
+                   graph_ms=round(sum(s["graph_ms"] for s in stats) / n, 1),
+                   level_kernel_ms=round(sum(s["level_kernel_ticks"] for s in stats) / n / 1e5, 1),
+                   chain_ms=round(sum(s["chain_wall_ticks"] for s in stats) / n / 1e5, 1),
+                   chain_mcycles=round(sum(s["chain_cycles"] for s in stats) / n / 1e6, 1),
+                   xcd=[sum(s["xcd_levels"][k] for s in stats) for k in range(8)],
+                   levels=round(sum(s["level_launches"] for s in stats) / n))
+        rec["t_end"] = t_end
+        rec["gap_us_per_level"] = round(1e3 * (rec["cluster_ms"] - rec["level_kernel_ms"]) / max(rec["levels"], 1), 1)
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
