@@ -11,9 +11,6 @@
 // HBM.
 #include <hip/hip_runtime.h>
 
-#include <sys/prctl.h>
-#include <time.h>
-
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -41,7 +38,8 @@ void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node
                          int* support);
 bool level_wants_grid(const JobDev& job, const LevelHdr& h);
 int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* Pd);
-void launch_level(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* P, LevelResult* R);
+int level_kind(const LevelHdr& h);
+void launch_level_batch(hipStream_t st, int kind, const LevelBatch& b, int n);
 void launch_msa(hipStream_t st, const MsaDev& d);
 void launch_thread(hipStream_t st, const ThreadDev& d, int* pool_sorted);
 int init_kernels();
@@ -144,6 +142,12 @@ struct HStrain {                      // host bookkeeping of one candidate (Stra
 struct PathRec { int node, parent; };
 
 struct Worker;
+// A level waiting for its launch: the worker's slot, the level's scalars and which kernel it needs.
+struct LevelRequest { Worker* w; LevelItem item; int kind; bool timed; };
+// Launch streams are shared by all regions in flight.  A stream carries one batch at a time (`busy` = regions of that
+// batch whose stamp has not been seen yet), so kernels of different regions never queue behind each other: a level
+// that finds every stream busy waits in `pending` and leaves with the next batch of its kind.
+struct LaunchStream { hipStream_t st = nullptr; int busy = 0; };
 struct Ctx {
     int device = 0;
     std::string last_error;
@@ -154,11 +158,22 @@ struct Ctx {
     int next_handle = 1;
     bool stop = false;
     std::vector<std::unique_ptr<Worker>> workers;
+    std::vector<LaunchStream> lstreams;
+    std::vector<hipStream_t> setup_streams;   // uploads, graph kernels: shared round-robin by the workers
+    // the level server: one thread launches every level and sees every completion stamp (serve_levels)
+    std::mutex dmu;                           // guards pending, server_stop
+    std::condition_variable dcv;              // the server sleeps here while nothing is pending or in flight
+    std::deque<LevelRequest> pending;         // requests the server has not taken yet
+    std::atomic<int> n_pending{0};
+    bool server_stop = false;
+    std::thread server;
+    void submit_level(const LevelRequest& rq);
+    void serve_levels();
     double* dU = nullptr;             // uniform stream on the device
     float* dUf = nullptr;             // fp32 copy
     int wait_mode = 0;                // how a worker waits for its level's stamp: WAIT_*
 };
-enum { WAIT_SPIN = 0, WAIT_SLEEP = 1, WAIT_EVENT = 2 };
+enum { WAIT_SPIN = 0, WAIT_SLEEP = 1 };
 
 // CPUs this process may use: the cgroup quota when there is one (a GPU box hands out a share of its host)
 static double cpu_budget() {
@@ -174,18 +189,22 @@ static double cpu_budget() {
     }
     return n > 0 ? n : 1;
 }
-static void sleep_us(double us) {
-    if (us <= 0) return;
-    timespec ts;
-    ts.tv_sec = (time_t)(us * 1e-6);
-    ts.tv_nsec = (long)((us - 1e6 * (double)ts.tv_sec) * 1e3);
-    nanosleep(&ts, nullptr);
-}
 
 struct Worker {
     Ctx* ctx;
     std::thread th;
-    hipStream_t st = nullptr;
+    int slot = 0;                     // worker index
+    hipStream_t st = nullptr;         // a setup stream of the context (not owned), or a private one (own_stream)
+    bool own_stream = false;
+    // hand-shake with the level server: 1 = a level is on its way / in flight, 2 = its stamp was seen, 3 = failed
+    std::atomic<int> level_state{0};
+    unsigned level_want = 0;          // stamp of that level
+    int cur_stream = -1;              // its launch stream (server's bookkeeping)
+    std::mutex wmu;
+    std::condition_variable wcv;
+    std::string level_err;
+    double t_batch_launched = 0;      // diagnostics: when the level's batch was launched, and its size
+    int batch_n = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
     LevelParams* Ph = nullptr;        // host-mapped: written here, read by the level's kernel over PCIe
     LevelParams* Pm = nullptr;        //   its device address
@@ -202,8 +221,7 @@ struct Worker {
     void init();
     void run();
     void process(Job& job);
-    void wait_level(unsigned want, double predicted_us);
-    double ns_per_draw = 0, plain_level_us = 0;      // what the last levels took, to size the sleep of WAIT_SLEEP
+    void wait_level();
     int msa_device(const std::vector<std::string>& seqs, std::vector<std::string>& rows);
     void thread_device(const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cig,
                        ThreadTables& T);
@@ -212,7 +230,7 @@ struct Worker {
 
 void Worker::init() {
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (!st) { HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
     HIPCHK(hipEventCreate(&ev0));
     HIPCHK(hipEventCreate(&ev1));
     HIPCHK(hipEventCreateWithFlags(&ev_sync, hipEventBlockingSync | hipEventDisableTiming));
@@ -224,40 +242,109 @@ void Worker::init() {
     std::memset(Rh, 0, sizeof(LevelResult));
 }
 
-// The level's kernel stores its stamp into host memory after everything else it reports (system-scope
-// release): the host sees the level finished without a stream synchronisation.  With more regions in flight
-// than cores, sleep on an event instead of spinning.
-void Worker::wait_level(unsigned want, double predicted_us) {
-    auto done = [&] { return __atomic_load_n(&Rh->seq, __ATOMIC_ACQUIRE) == want; };
-    auto check_stream = [&] {
-        const hipError_t e = hipStreamQuery(st);
-        if (e == hipSuccess) {
-            if (!done()) throw HipError("a level kernel ended without its completion stamp");
-        } else if (e != hipErrorNotReady) {
-            throw HipError(std::string("level kernel: ") + hipGetErrorString(e));
-        }
+// The level server.  Workers hand their next level to this thread and wait; it is the only thread that launches level
+// kernels and the only one that watches the completion stamps, so a finished level is seen within a microsecond
+// however many regions are in flight, and nobody polls or contends for the launch path.
+//   * A level's kernel stores its stamp into host memory after everything else it reports (system-scope release):
+//     completion is seen without a stream synchronisation.
+//   * Launch streams are shared by all regions.  A stream carries one batch at a time, so kernels of different
+//     regions never queue behind each other; while a stream is free, the oldest waiting level and every other waiting
+//     level that needs the same kernel (up to MAXB) leave together as one grid (workgroup b = region b of the batch).
+void Ctx::serve_levels() {
+    (void)hipSetDevice(device);
+    std::deque<LevelRequest> waiting;          // taken from `pending`, not launched yet
+    std::vector<Worker*> flying;               // launched, stamp not seen yet
+    std::string dead;                          // non-empty: a launch stream has failed, every level fails from now on
+    auto finish = [](Worker* w, int state, const std::string& err) {
+        { std::lock_guard<std::mutex> lk(w->wmu); w->level_err = err; w->level_state.store(state, std::memory_order_release); }
+        w->wcv.notify_one();
     };
-    if (ctx->wait_mode == WAIT_EVENT) {
-        HIPCHK(hipEventRecord(ev_sync, st));
-        HIPCHK(hipEventSynchronize(ev_sync));
-        if (!done()) throw HipError("a level kernel ended without its completion stamp");
-        return;
-    }
-    if (ctx->wait_mode == WAIT_SLEEP) {
-        // more regions in flight than this process has cores: sleep through most of the level, then look every few tens of microseconds
-        if (predicted_us > 80) sleep_us(0.85 * predicted_us - 20);
-        unsigned polls = 0;
-        while (!done()) {
-            sleep_us(20);
-            if ((++polls & 0x3FFu) == 0) check_stream();
+    unsigned idle_spins = 0;
+    for (;;) {
+        if (n_pending.load(std::memory_order_acquire) > 0 || (waiting.empty() && flying.empty())) {
+            std::unique_lock<std::mutex> lk(dmu);
+            if (waiting.empty() && flying.empty()) dcv.wait(lk, [&] { return server_stop || !pending.empty(); });
+            if (server_stop) break;
+            while (!pending.empty()) { waiting.push_back(pending.front()); pending.pop_front(); }
+            n_pending.store(0, std::memory_order_release);
         }
-        return;
-    }
-    unsigned spins = 0;
-    while (!done()) {
+        bool progressed = false;
+        // completions
+        for (size_t i = 0; i < flying.size();) {
+            Worker* w = flying[i];
+            if (__atomic_load_n(&w->Rh->seq, __ATOMIC_ACQUIRE) == w->level_want) {
+                lstreams[(size_t)w->cur_stream].busy--;
+                w->cur_stream = -1;
+                flying[i] = flying.back(); flying.pop_back();
+                finish(w, 2, "");
+                progressed = true;
+            } else {
+                ++i;
+            }
+        }
+        // launches
+        while (!waiting.empty()) {
+            if (!dead.empty()) { finish(waiting.front().w, 3, dead); waiting.pop_front(); progressed = true; continue; }
+            int fs = -1;
+            for (size_t i = 0; i < lstreams.size(); i++) if (lstreams[i].busy == 0) { fs = (int)i; break; }
+            if (fs < 0) break;
+            const int kind = waiting.front().kind;
+            LevelBatch batch;
+            Worker* who[MAXB];
+            int n = 0;
+            bool timed = false;
+            for (auto it = waiting.begin(); it != waiting.end() && n < MAXB;) {
+                if (it->kind != kind) { ++it; continue; }
+                batch.it[n] = it->item;
+                who[n++] = it->w;
+                timed = timed || it->timed;
+                it = waiting.erase(it);
+            }
+            hipStream_t st = lstreams[(size_t)fs].st;
+            if (timed) for (int i = 0; i < n; i++) (void)hipEventRecord(who[i]->ev0, st);
+            launch_level_batch(st, kind, batch, n);
+            if (timed) for (int i = 0; i < n; i++) (void)hipEventRecord(who[i]->ev1, st);
+            lstreams[(size_t)fs].busy = n;
+            const double tl = now_ms();
+            for (int i = 0; i < n; i++) { who[i]->cur_stream = fs; who[i]->t_batch_launched = tl; who[i]->batch_n = n; flying.push_back(who[i]); }
+            progressed = true;
+        }
+        if (progressed) { idle_spins = 0; continue; }
         __builtin_ia32_pause();
-        if ((++spins & 0x3FFFFu) == 0) check_stream();   // every few milliseconds: has the stream died?
+        if ((++idle_spins & 0xFFFFFu) == 0) {
+            // nothing has moved for a while: has a stream died under its batch?
+            for (auto& ls : lstreams) {
+                if (ls.busy == 0) continue;
+                const hipError_t e = hipStreamQuery(ls.st);
+                if (e != hipSuccess && e != hipErrorNotReady) dead = std::string("level kernel: ") + hipGetErrorString(e);
+            }
+            if (!dead.empty()) {
+                for (Worker* w : flying) { lstreams[(size_t)w->cur_stream].busy = 0; w->cur_stream = -1; finish(w, 3, dead); }
+                flying.clear();
+            }
+        }
     }
+    for (Worker* w : flying) finish(w, 3, "context destroyed");
+    for (auto& rq : waiting) finish(rq.w, 3, "context destroyed");
+}
+void Ctx::submit_level(const LevelRequest& rq) {
+    rq.w->level_state.store(1, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> lk(dmu);
+        pending.push_back(rq);
+        n_pending.fetch_add(1, std::memory_order_release);
+    }
+    dcv.notify_one();
+}
+// Few regions in flight: spin (the server's hand-over is seen at once); more regions than this process has cores: sleep.
+void Worker::wait_level() {
+    if (ctx->wait_mode == WAIT_SPIN) {
+        while (level_state.load(std::memory_order_acquire) == 1) __builtin_ia32_pause();
+    } else {
+        std::unique_lock<std::mutex> lk(wmu);
+        wcv.wait(lk, [&] { return level_state.load(std::memory_order_acquire) != 1; });
+    }
+    if (level_state.load(std::memory_order_acquire) == 3) throw HipError(level_err);
 }
 
 // a7 on the device.  Returns the number of columns.
@@ -532,7 +619,8 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     long sampler_launches = 0, level_launches = 0, draws = 0, exact = 0, slow = 0, sampler_copies = 0, sampler_strains = 0, passes = 0;
     unsigned long long chain_cycles = 0, chain_wall = 0, level_ticks = 0;
 
-    FILE* level_log = getenv("SC_LEVEL_LOG") ? fopen(getenv("SC_LEVEL_LOG"), "a") : nullptr;   // diagnostics only
+    double t_last_done = now_ms();
+    FILE* level_log = getenv("SC_LEVEL_LOG") ? fopen((std::string(getenv("SC_LEVEL_LOG")) + "." + std::to_string(slot)).c_str(), "a") : nullptr;   // diagnostics only
     auto run_level = [&](int mode, int e0, int e1, int Q, int n_sweeps, bool do_update, const std::vector<HStrain>& sv,
                          bool has_dups, bool any_multi) {
         LevelParams& P = *Ph;
@@ -570,14 +658,13 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             const size_t bytes = offsetof(LevelParams, lpt) + sizeof(double) * (size_t)S * KK;
             HIPCHK(hipMemcpyAsync(Pd, Ph, bytes, hipMemcpyHostToDevice, st));
             H.done = launch_level_grid(st, jd, H, Pd);
+            HIPCHK(hipStreamSynchronize(st));            // the level's kernel runs on another stream
         }
         H.seq = ++seq;
-        if (timed) HIPCHK(hipEventRecord(ev0, st));
-        launch_level(st, jd, H, Pm, Rd);
-        if (timed) HIPCHK(hipEventRecord(ev1, st));
-        wait_level(H.seq, chain ? ns_per_draw * 1e-3 * (double)n_sweeps * Q : plain_level_us);
-        if (chain && n_sweeps * Q > 0) ns_per_draw = 10.0 * (double)Rh->level_wall / ((double)n_sweeps * Q);
-        else plain_level_us = 0.01 * (double)Rh->level_wall;
+        level_want = H.seq;
+        const double t_launched = level_log ? now_ms() : 0.0;
+        ctx->submit_level(LevelRequest{this, LevelItem{jd, H, Pm, Rd}, level_kind(H), timed});
+        wait_level();
         if (timed) HIPCHK(hipEventSynchronize(ev1));
         level_launches++;
         if (chain) {
@@ -586,9 +673,16 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             chain_cycles += Rh->chain_cycles; chain_wall += Rh->chain_wall;
         }
         level_ticks += Rh->level_wall;
-        if (level_log) fprintf(level_log, "h %d mode %d S %d Q %d n %d level_us %.1f chain_us %.1f cyc %llu passes %llu slow %llu xcc %d\n", job.handle, mode, S, Q,
-                               n_sweeps, Rh->level_wall * 0.01, chain ? Rh->chain_wall * 0.01 : 0.0, chain ? (unsigned long long)Rh->chain_cycles : 0ull,
-                               chain ? (unsigned long long)Rh->n_pass : 0ull, chain ? (unsigned long long)Rh->n_slow : 0ull, Rh->xcc);
+        if (level_log) {
+            const double t_done = now_ms();
+            fprintf(level_log, "h %d mode %d S %d Q %d n %d level_us %.1f chain_us %.1f cyc %llu passes %llu slow %llu xcc %d ncopy %d multi %d "
+                    "ph %.1f %.1f %.1f %.1f %.1f host_us %.1f wait_us %.1f pend_us %.1f batch %d\n", job.handle, mode, S, Q,
+                    n_sweeps, Rh->level_wall * 0.01, chain ? Rh->chain_wall * 0.01 : 0.0, chain ? (unsigned long long)Rh->chain_cycles : 0ull,
+                    chain ? (unsigned long long)Rh->n_pass : 0ull, chain ? (unsigned long long)Rh->n_slow : 0ull, Rh->xcc, H.n_copy, (int)any_multi,
+                    Rh->phase_ticks[0] * 0.01, Rh->phase_ticks[1] * 0.01, Rh->phase_ticks[2] * 0.01, Rh->phase_ticks[3] * 0.01, Rh->phase_ticks[4] * 0.01,
+                    1e3 * (t_launched - t_last_done), 1e3 * (t_done - t_launched), 1e3 * (t_batch_launched - t_launched), batch_n);
+            t_last_done = t_done;
+        }
         job.stats.xcd_levels[Rh->xcc & 7]++;
         if (timed) {
             float ms = 0;
@@ -862,7 +956,6 @@ void Worker::process(Job& job) {
 }
 
 void Worker::run() {
-    prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0);          // nanosleep of WAIT_SLEEP: wake within ~2 us of the timer, not the default 50
     try { init(); } catch (const std::exception& ex) {
         std::lock_guard<std::mutex> lk(ctx->mu);
         ctx->last_error = ex.what();
@@ -901,10 +994,9 @@ extern "C" {
 int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
     if (!out) return SC_ERR_ARG;
     *out = nullptr;
-    if (stream_count > 4 && !getenv("GPU_MAX_HW_QUEUES")) {
-        // one hardware queue per region in flight; only effective if HIP is not initialised yet
-        setenv("GPU_MAX_HW_QUEUES", std::to_string(stream_count > 24 ? 24 : stream_count).c_str(), 0);
-    }
+    // 16 hardware queues run side by side on this GPU (more are time-sliced: measured); the launch and setup streams below
+    // want one each.  Only effective if HIP is not initialised yet in this process (rambl_amd/__init__.py sets it too).
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SC_ERR_NO_DEVICE;
     hipDeviceProp_t prop;
@@ -928,20 +1020,35 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         return SC_ERR_HIP;
     }
     if (stream_count < 1) stream_count = 1;
-    if (stream_count > 64) stream_count = 64;
+    if (stream_count > 256) stream_count = 256;
+    {
+        const char* e = getenv("SC_LAUNCH_STREAMS");
+        int nl = e ? atoi(e) : 12;
+        nl = nl < 1 ? 1 : (nl > 30 ? 30 : nl);
+        if (nl > stream_count) nl = stream_count;
+        const int nset = stream_count > 1 ? 2 : 1;
+        ctx->lstreams.resize((size_t)nl);
+        ctx->setup_streams.resize((size_t)nset);
+        bool ok = true;
+        for (auto& ls : ctx->lstreams) ok = ok && hipStreamCreateWithFlags(&ls.st, hipStreamNonBlocking) == hipSuccess;
+        for (auto& ss : ctx->setup_streams) ok = ok && hipStreamCreateWithFlags(&ss, hipStreamNonBlocking) == hipSuccess;
+        if (!ok) { sc_ctx_destroy(h); return SC_ERR_HIP; }
+    }
     {
         // spinning workers see their level's stamp at once, but only while every one of them has a core
         const char* e = getenv("SC_WAIT");
         if (e && !std::strcmp(e, "spin")) ctx->wait_mode = WAIT_SPIN;
         else if (e && !std::strcmp(e, "sleep")) ctx->wait_mode = WAIT_SLEEP;
-        else if (e && !std::strcmp(e, "event")) ctx->wait_mode = WAIT_EVENT;
         else ctx->wait_mode = ((double)stream_count + 2 <= 0.6 * cpu_budget()) ? WAIT_SPIN : WAIT_SLEEP;
     }
     for (int i = 0; i < stream_count; i++) {
         auto w = std::make_unique<Worker>();
         w->ctx = ctx;
+        w->slot = i;
+        w->st = ctx->setup_streams[(size_t)i % ctx->setup_streams.size()];
         ctx->workers.push_back(std::move(w));
     }
+    ctx->server = std::thread([ctx] { ctx->serve_levels(); });
     for (auto& w : ctx->workers) w->th = std::thread([p = w.get()] { p->run(); });
     *out = h;
     return SC_OK;
@@ -953,6 +1060,9 @@ void sc_ctx_destroy(sc_ctx* h) {
     { std::lock_guard<std::mutex> lk(ctx->mu); ctx->stop = true; }
     ctx->cv_job.notify_all();
     for (auto& w : ctx->workers) if (w->th.joinable()) w->th.join();
+    { std::lock_guard<std::mutex> lk(ctx->dmu); ctx->server_stop = true; }
+    ctx->dcv.notify_all();
+    if (ctx->server.joinable()) ctx->server.join();
     (void)hipSetDevice(ctx->device);
     for (auto& w : ctx->workers) {
         if (w->Ph) (void)hipHostFree(w->Ph);
@@ -961,9 +1071,12 @@ void sc_ctx_destroy(sc_ctx* h) {
         if (w->ev0) (void)hipEventDestroy(w->ev0);
         if (w->ev1) (void)hipEventDestroy(w->ev1);
         if (w->ev_sync) (void)hipEventDestroy(w->ev_sync);
-        if (w->st) (void)hipStreamDestroy(w->st);
+        if (w->st && w->own_stream) (void)hipStreamDestroy(w->st);
     }
     ctx->workers.clear();
+    for (auto& ls : ctx->lstreams) if (ls.st) (void)hipStreamDestroy(ls.st);
+    for (auto& ss : ctx->setup_streams) if (ss) (void)hipStreamDestroy(ss);
+
     if (ctx->dU) (void)hipFree(ctx->dU);
     if (ctx->dUf) (void)hipFree(ctx->dUf);
     delete h;

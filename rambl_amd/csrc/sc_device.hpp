@@ -75,6 +75,21 @@ struct LevelParams {
     double lpt[MAXS * KK];       // log sub(a,b) - log comp(a) per strain
 };
 
+// One launch serves the current level of up to MAXB regions: workgroup b takes batch.it[b].  Everything the
+// level needs to find its region travels in the kernel-argument segment (scalar loads the compiler can repeat
+// instead of holding registers): the region's arrays, the level's scalars, the host-mapped parameter / result
+// blocks.  MAXB keeps the segment below 4 KB.
+struct LevelParams;
+struct LevelResult;
+struct LevelItem {
+    JobDev job;
+    LevelHdr h;
+    const LevelParams* P;        // host-mapped
+    LevelResult* R;              // host-mapped
+};
+constexpr int MAXB = 14;
+struct LevelBatch { LevelItem it[MAXB]; };
+
 // Per-level results, written by the kernel into host-mapped pinned memory; `seq` last (system-scope release).
 struct LevelResult {
     double abund[MAXS];          // HARD: sum of responsibilities; SAMPLE: urn weights a[] after the sweeps
@@ -87,6 +102,7 @@ struct LevelResult {
     unsigned long long chain_cycles, chain_wall;   // shader cycles / 100 MHz ticks spent in the urn chain
     unsigned long long n_exact;  // draws resolved by the literal fp64 path
     unsigned long long level_wall;                 // 100 MHz ticks from the start of the level's kernel to its end
+    unsigned phase_ticks[6];     // diagnostics: 100 MHz ticks at the end of staging / copies / update / slots / table / chain
     int error;
     int xcc;                     // XCD the level's workgroup ran on (HW_REG_XCC_ID)
     unsigned seq;                // == LevelHdr::seq once every other field is in place

@@ -669,6 +669,7 @@ __device__ __forceinline__ void finish_level(const LevelHdr& h, LevelResult* __r
     if (tid == 0) {
         R->level_wall = wall_clock64() - wall0;
         R->xcc = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xF);      // HW_REG_XCC_ID[3:0]
+        R->xcc = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xF);      // HW_REG_XCC_ID[3:0]
         __hip_atomic_store(&R->seq, h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -715,10 +716,14 @@ constexpr int CHAIN_THREADS = 512;   // eight wavefronts build the level
 // small (the pass is latency-bound and a wider window accepts more draws), four otherwise (the others leave)
 constexpr int chain_nw(int nb) { return nb <= 2 ? 8 : 4; }
 template <int NB, bool ROWS_LDS>
-__global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(JobDev job, LevelHdr h, const LevelParams* __restrict__ P,
-                                                                LevelResult* __restrict__ R) {
+__global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(LevelBatch batch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const unsigned long long wall0 = wall_clock64();
+    const LevelItem& it = batch.it[blockIdx.x];
+    const LevelHdr& h = it.h;
+    const JobDev& job = it.job;
+    const LevelParams* __restrict__ P = it.P;
+    LevelResult* __restrict__ R = it.R;
     const LevelLds l = level_lds(s_raw);
     float* s_uwin = reinterpret_cast<float*>(l.s_big);           // [UWIN]
     float* s_rows = s_uwin + UWIN;
@@ -731,14 +736,18 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(JobDev job, Leve
     for (int i = tid; i < MAXS * KMAX; i += nt) l.s_cnt[i] = 0;
     if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_pass = 0; R->chain_cycles = 0; R->chain_wall = 0; }
     __syncthreads();
+    if (tid == 0) R->phase_ticks[0] = (unsigned)(wall_clock64() - wall0);
     if (tid < MAXS) {
         l.s_slot[tid] = tid < S ? l.s_sp[tid].slot : 0;
         l.s_kf[tid] = 0u;
         l.s_a0f[tid] = tid < S ? (float)l.s_sp[tid].a0 : 0.0f;
     }
     phase_copies(job, h, l.s_copy, tid, nt);
+    if (tid == 0) R->phase_ticks[1] = (unsigned)(wall_clock64() - wall0);
     if (upd) phase_update(job, h, l.s_sp, reinterpret_cast<const double*>(l.s_big), tid, nt);
+    if (tid == 0) R->phase_ticks[2] = (unsigned)(wall_clock64() - wall0);
     phase_slots(job, h, tid, nt);
+    if (tid == 0) R->phase_ticks[3] = (unsigned)(wall_clock64() - wall0);
 
     // what the sampler draws from.  Per draw slot q the fp32 weight row L[q][s] = exp(x_s - max_s x_s),
     // x_s = ll(read) + ll(mate) in fp64, with the read's symbol behind it.  G lanes share a slot, each walks
@@ -789,6 +798,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(JobDev job, Leve
         }
     }
     __syncthreads();
+    if (tid == 0) R->phase_ticks[4] = (unsigned)(wall_clock64() - wall0);
     constexpr int NW = chain_nw(NB);
     if (tid >= 64 * NW) return;                            // a finished wavefront no longer counts at the barriers below
     nt = 64 * NW;
@@ -801,9 +811,14 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(JobDev job, Leve
 // --------------------------------------------------------------------------
 // a13 + a15: one level without the sampler in one launch -- the read log-likelihood update, and for MODE_HARD
 // the soft update hard_clustering (NonparametricClustering.cpp:17-125).  Single workgroup.
-__global__ __launch_bounds__(512) void k_level(JobDev job, LevelHdr h, const LevelParams* __restrict__ P, LevelResult* __restrict__ R) {
+__global__ __launch_bounds__(512) void k_level(LevelBatch batch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const unsigned long long wall0 = wall_clock64();
+    const LevelItem& it = batch.it[blockIdx.x];
+    const LevelHdr& h = it.h;
+    const JobDev& job = it.job;
+    const LevelParams* __restrict__ P = it.P;
+    LevelResult* __restrict__ R = it.R;
     const LevelLds l = level_lds(s_raw);
     double* s_tab = reinterpret_cast<double*>(l.s_big);          //   [MAXS*KK] lpt, later the substitution histogram
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -813,10 +828,14 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, LevelHdr h, const Lev
     stage_params(h, P, l.s_sp, l.s_copy, s_tab, upd && !(h.done & LV_ITEMS_DONE), tid, nt);
     if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_pass = 0; R->chain_cycles = 0; R->chain_wall = 0; }
     __syncthreads();
+    if (tid == 0) R->phase_ticks[0] = (unsigned)(wall_clock64() - wall0);
     phase_copies(job, h, l.s_copy, tid, nt);
+    if (tid == 0) R->phase_ticks[1] = (unsigned)(wall_clock64() - wall0);
     if (upd) phase_update(job, h, l.s_sp, s_tab, tid, nt);
+    if (tid == 0) R->phase_ticks[2] = (unsigned)(wall_clock64() - wall0);
     if (Rn <= 0 || S <= 0 || h.mode != MODE_HARD) { finish_level(h, R, wall0, tid); return; }
     phase_slots(job, h, tid, nt);
+    if (tid == 0) R->phase_ticks[3] = (unsigned)(wall_clock64() - wall0);
 
     // hard_clustering, NonparametricClustering.cpp:17-125
     const int Q = h.Q;
@@ -857,6 +876,7 @@ __global__ __launch_bounds__(512) void k_level(JobDev job, LevelHdr h, const Lev
     }
     for (int i = tid; i < S * KK; i += nt) s_tab[i] = 0.0;
     __syncthreads();
+    if (tid == 0) R->phase_ticks[4] = (unsigned)(wall_clock64() - wall0);
     if (!h.any_multi) {
         // thread (s, b): responsibilities summed in draw-slot order, as the reference adds them
         for (int idx = tid; idx < S * (K + 1); idx += nt) {
@@ -1234,7 +1254,7 @@ int init_kernels() {
     rc |= set_sample_attr<8, true>(); rc |= set_sample_attr<8, false>();
     return rc;
 }
-// A level of ordinary size is ONE launch (launch_level).  Only when a level has so many (strain, read) items or
+// A level of ordinary size is ONE launch (launch_level_batch).  Only when a level has so many (strain, read) items or
 // such long rows that a single workgroup would crawl (unthinned deep coverage) do the row copies and the
 // single-symbol update run on a grid first; `Pd` is then a device copy of the parameters the caller has put
 // in front of these launches on the same stream.  Returns the LV_* bits to pass on in LevelHdr::done.
@@ -1263,21 +1283,30 @@ int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, cons
     }
     return done;
 }
-// One level = one launch: S, Q of the level decide the sampler variant and whether the fp32 rows fit in LDS.
-void launch_level(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* P, LevelResult* R) {
+// One launch = the current level of `n` regions whose levels need the same kernel (workgroup b = batch.it[b]).
+// kind 0: no sampler (k_level); kind 1 + 2 * (NB - 1) + L: the sampler variant for NB = ceil(S / 16) register
+// blocks, L = weight rows fit in LDS.
+int level_kind(const LevelHdr& h) {
     const int S = h.S, Q = h.Q, Rn = h.e1 - h.e0;
     const bool chain = h.mode == MODE_SAMPLE && h.n_sweeps > 0 && S > 1 && Rn > 0;
-    if (!chain) {
-        hipLaunchKernelGGL(k_level, dim3(1), dim3(512), LEVEL_LDS, st, job, h, P, R);
+    if (!chain) return 0;
+    const bool wl = ((long)Q * chain_w_stride(S) + 16) * 4 <= (long)CHAINW_ROWS_BYTES;
+    int nb = (S + 15) / 16;
+    nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+    return 1 + 2 * (nb - 1) + (wl ? 1 : 0);
+}
+void launch_level_batch(hipStream_t st, int kind, const LevelBatch& b, int n) {
+    if (kind == 0) {
+        hipLaunchKernelGGL(k_level, dim3(n), dim3(512), LEVEL_LDS, st, b);
         return;
     }
-    const bool wl = ((long)Q * chain_w_stride(S) + 16) * 4 <= (long)CHAINW_ROWS_BYTES;
-#define SC_SAMPLE(NB) case NB: if (wl) hipLaunchKernelGGL((k_level_sample<NB, true>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, h, P, R); \
-                               else hipLaunchKernelGGL((k_level_sample<NB, false>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, h, P, R); break;
-    switch ((S + 15) / 16) {
+    const bool wl = (kind - 1) & 1;
+#define SC_SAMPLE(NB) case NB: if (wl) hipLaunchKernelGGL((k_level_sample<NB, true>), dim3(n), dim3(CHAIN_THREADS), CHAIN_LDS, st, b); \
+                               else hipLaunchKernelGGL((k_level_sample<NB, false>), dim3(n), dim3(CHAIN_THREADS), CHAIN_LDS, st, b); break;
+    switch ((kind - 1) / 2 + 1) {
         SC_SAMPLE(1) SC_SAMPLE(2) SC_SAMPLE(3) SC_SAMPLE(4) SC_SAMPLE(5) SC_SAMPLE(6) SC_SAMPLE(7)
-        default: if (wl) hipLaunchKernelGGL((k_level_sample<8, true>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, h, P, R);
-                 else hipLaunchKernelGGL((k_level_sample<8, false>), dim3(1), dim3(CHAIN_THREADS), CHAIN_LDS, st, job, h, P, R);
+        default: if (wl) hipLaunchKernelGGL((k_level_sample<8, true>), dim3(n), dim3(CHAIN_THREADS), CHAIN_LDS, st, b);
+                 else hipLaunchKernelGGL((k_level_sample<8, false>), dim3(n), dim3(CHAIN_THREADS), CHAIN_LDS, st, b);
     }
 #undef SC_SAMPLE
 }

@@ -57,6 +57,8 @@ def main():
         if os.environ.get("SC_PROBE_START"):
             while time.time() < float(os.environ["SC_PROBE_START"]):
                 time.sleep(0.0005)
+        import resource
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.time()
         _, stats = stage5.run_regions(ctx, prep[:r], r, params)
         t_end = time.time()
@@ -71,6 +73,8 @@ def main():
                    chain_mcycles=round(sum(s["chain_cycles"] for s in stats) / n / 1e6, 1),
                    xcd=[sum(s["xcd_levels"][k] for s in stats) for k in range(8)],
                    levels=round(sum(s["level_launches"] for s in stats) / n))
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        rec["cpu_cores_used"] = round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / dt, 2)
         rec["t_end"] = t_end
         rec["gap_us_per_level"] = round(1e3 * (rec["cluster_ms"] - rec["level_kernel_ms"]) / max(rec["levels"], 1), 1)
         print(json.dumps(rec), flush=True)
