@@ -129,6 +129,39 @@ int sc_roi_edge_support(sc_ctx* ctx, int handle, int* support, int cap, int* n_e
 int sc_roi_thread_tables(sc_ctx* ctx, int handle, int* count, int* first_read, int cls_cap, int* pool, long pool_cap,
                          char* symbols, int* n_cls, long* n_pool);
 
+/* ---- rows a2-a4 on the host: the alignment file and a window's reads (rambl_amd/csrc/sc_ingest.cpp) ----------
+ *
+ * The reference shells out to samtools for every window (StrainCall.cpp:496 `view -q mq -F 1804 region`, :696
+ * `mpileup -q mq -Q0 -A -r region`) and parses the text.  Here the file (SAM text, or BAM read natively: BGZF +
+ * the record layout of the SAM specification, section 4) is read once and indexed by reference name. */
+typedef struct sc_aln sc_aln;
+typedef struct sc_reads sc_reads;
+
+int sc_aln_open(const char* path, sc_aln** out);     /* on a parse error *out still carries the message */
+void sc_aln_close(sc_aln* aln);
+const char* sc_aln_error(sc_aln* aln);
+long sc_aln_records(sc_aln* aln);
+/* alignments of one reference and the reference bases they cover: what a scheduler needs to price a region */
+int sc_aln_ref_stats(sc_aln* aln, const char* gene, long* n_records, long* aligned_bases);
+
+/* What window_adjust reads out of the pileup of gene:P-Q (StrainCall.cpp:702-736): for position P+i, whether any
+ * read covers it, and whether column 5 of its pileup line would hold a '+' (insertion) / a '-' or '*' (deletion) --
+ * including the mapping-quality character after '^' that the reference mistakes for one.  Arrays of Q-P+1 bytes. */
+int sc_aln_pileup_flags(sc_aln* aln, const char* gene, int P, int Q, int mq, unsigned char* covered,
+                        unsigned char* has_ins, unsigned char* has_del);
+
+/* load_mapping_reads (StrainCall.cpp:480-670) for the window gene:p0-p1: view filter, depth -> keep probability,
+ * length / N / insertion filters, crop to the window, mt19937(1234) thinning (drawn only for reads that pass),
+ * exact-duplicate collapse in (position, CIGAR, bases) order, mate table. */
+int sc_aln_load_reads(sc_aln* aln, const char* gene, int p0, int p1, int mq, int rl, int max_ins, int max_depth,
+                      sc_reads** out);
+/* The packed arrays sc_roi_submit takes, owned by `reads` (valid until sc_reads_free); n_input = alignments the
+ * view returned, depth = the integer mean depth the keep probability came from. */
+int sc_reads_get(sc_reads* reads, int* n_reads, const int** pos, const char** cigar_text, const int** cigar_off,
+                 const char** seq_text, const int** seq_off, const int** copies, const int** mate_idx,
+                 const int** mate_off, long* n_input, int* depth);
+void sc_reads_free(sc_reads* reads);
+
 #ifdef __cplusplus
 }
 #endif

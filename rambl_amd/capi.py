@@ -57,6 +57,23 @@ def load_library():
     lib.sc_roi_edge_support.argtypes = [vp, C.c_int, ip, C.c_int, ip]
     lib.sc_msa_align.argtypes = [vp, cp, ip, C.c_int, C.c_char_p, C.c_long, ip]
     lib.sc_roi_thread_tables.argtypes = [vp, C.c_int, ip, ip, C.c_int, ip, C.c_long, C.c_char_p, ip, C.POINTER(C.c_long)]
+    pi, pc, pu = C.POINTER(ip), C.POINTER(C.c_char_p), C.POINTER(C.c_ubyte)
+    lib.sc_aln_open.argtypes = [cp, C.POINTER(vp)]
+    lib.sc_aln_close.argtypes = [vp]
+    lib.sc_aln_close.restype = None
+    lib.sc_aln_error.argtypes = [vp]
+    lib.sc_aln_error.restype = cp
+    lib.sc_aln_records.argtypes = [vp]
+    lib.sc_aln_records.restype = C.c_long
+    lib.sc_aln_ref_stats.argtypes = [vp, cp, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    lib.sc_aln_ref_stats.restype = C.c_int
+    lib.sc_aln_pileup_flags.argtypes = [vp, cp, C.c_int, C.c_int, C.c_int, pu, pu, pu]
+    lib.sc_aln_load_reads.argtypes = [vp, cp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.sc_reads_get.argtypes = [vp, ip, pi, pc, pi, pc, pi, pi, pi, pi, C.POINTER(C.c_long), ip]
+    lib.sc_reads_free.argtypes = [vp]
+    lib.sc_reads_free.restype = None
+    for f in ("sc_aln_open", "sc_aln_pileup_flags", "sc_aln_load_reads", "sc_reads_get"):
+        getattr(lib, f).restype = C.c_int
     for f in ("sc_ctx_create", "sc_roi_submit", "sc_roi_wait", "sc_roi_result", "sc_roi_graph_dump", "sc_roi_trace",
               "sc_roi_stats", "sc_roi_release", "sc_roi_edge_support", "sc_msa_align", "sc_roi_thread_tables"):
         getattr(lib, f).restype = C.c_int
@@ -65,7 +82,8 @@ def load_library():
 
 EXPORTS = ["sc_ctx_create", "sc_ctx_destroy", "sc_last_error", "sc_roi_submit", "sc_roi_wait", "sc_roi_result",
            "sc_roi_graph_dump", "sc_roi_trace", "sc_roi_stats", "sc_roi_release", "sc_roi_edge_support", "sc_msa_align",
-           "sc_roi_thread_tables"]
+           "sc_roi_thread_tables", "sc_aln_open", "sc_aln_close", "sc_aln_error", "sc_aln_records", "sc_aln_ref_stats", "sc_aln_pileup_flags",
+           "sc_aln_load_reads", "sc_reads_get", "sc_reads_free"]
 
 
 def default_params(error_rate=0.01, tau=0.02, diff_rate=0.01, graph_only=False, want_trace=False, want_timing=False, want_graph=False):
@@ -80,6 +98,121 @@ def _pack(strings):
         n += len(s)
     off[len(strings)] = n
     return "".join(strings).encode("ascii"), off
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = load_library()
+    return _LIB
+
+
+class NativeReads:
+    """A window's reads as load_mapping_reads leaves them (rows a2-a4), held by the library as the packed arrays
+    sc_roi_submit takes.  The list views (pos, cigar, seq, copies, mates) are built on demand, for tests and tools."""
+
+    def __init__(self, handle, gene_seq):
+        self._h = handle
+        self.gene_seq = gene_seq
+        n, depth, n_in = C.c_int(), C.c_int(), C.c_long()
+        ip = C.POINTER(C.c_int)
+        self._pos, self._cig_off, self._seq_off, self._cn, self._mate_idx, self._mate_off = ip(), ip(), ip(), ip(), ip(), ip()
+        self._cig, self._seq = C.c_char_p(), C.c_char_p()
+        rc = lib().sc_reads_get(handle, C.byref(n), C.byref(self._pos), C.byref(self._cig), C.byref(self._cig_off), C.byref(self._seq),
+                                C.byref(self._seq_off), C.byref(self._cn), C.byref(self._mate_idx), C.byref(self._mate_off),
+                                C.byref(n_in), C.byref(depth))
+        if rc != SC_OK:
+            raise StrainCallError(rc)
+        self.n = n.value
+        self.n_input = n_in.value          # alignments the view returned for the window
+        self.depth = depth.value
+
+    def __len__(self):
+        return self.n
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sc_reads_free(self._h)
+            self._h = None
+
+    def _texts(self, text, off):
+        raw = C.string_at(text, off[self.n]) if self.n else b""
+        return [raw[off[i]:off[i + 1]].decode("ascii") for i in range(self.n)]
+
+    @property
+    def pos(self):
+        return [self._pos[i] for i in range(self.n)]
+
+    @property
+    def copies(self):
+        return [self._cn[i] for i in range(self.n)]
+
+    @property
+    def cigar(self):
+        return self._texts(self._cig, self._cig_off)
+
+    @property
+    def seq(self):
+        return self._texts(self._seq, self._seq_off)
+
+    @property
+    def mates(self):
+        return [[self._mate_idx[k] for k in range(self._mate_off[i], self._mate_off[i + 1])] for i in range(self.n)]
+
+
+class NativeAln:
+    """An alignment file (SAM text or BAM) read and indexed by the library (sc_aln_*)."""
+
+    def __init__(self, path):
+        self.path = path
+        self._h = C.c_void_p()
+        rc = lib().sc_aln_open(path.encode(), C.byref(self._h))
+        if rc != SC_OK:
+            msg = lib().sc_aln_error(self._h).decode() if self._h else "cannot open"
+            self.close()
+            raise StrainCallError(rc, "%s: %s" % (path, msg))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sc_aln_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+    def records(self):
+        return lib().sc_aln_records(self._h)
+
+    def ref_stats(self, gene):
+        """(alignments of the reference, reference bases they cover)."""
+        n, b = C.c_long(), C.c_long()
+        lib().sc_aln_ref_stats(self._h, gene.encode(), C.byref(n), C.byref(b))
+        return n.value, b.value
+
+    def pileup_flags(self, mq, gene, P, Q):
+        """{position: (has_insert, has_delete)} for the covered positions of gene:P-Q."""
+        import numpy as np
+        n = Q - P + 1
+        if n <= 0:
+            return {}
+        cov, ins, dele = (np.zeros(n, dtype=np.uint8) for _ in range(3))
+        pu = C.POINTER(C.c_ubyte)
+        rc = lib().sc_aln_pileup_flags(self._h, gene.encode(), P, Q, mq, cov.ctypes.data_as(pu), ins.ctypes.data_as(pu),
+                                       dele.ctypes.data_as(pu))
+        if rc != SC_OK:
+            raise StrainCallError(rc)
+        idx = np.nonzero(cov)[0]
+        return {int(k) + P: (bool(ins[k]), bool(dele[k])) for k in idx}
+
+    def load_reads(self, gene_seq, gene, p0, p1, mq, rl, max_ins, max_depth):
+        h = C.c_void_p()
+        rc = lib().sc_aln_load_reads(self._h, gene.encode(), p0, p1, mq, rl, max_ins, max_depth, C.byref(h))
+        if rc != SC_OK:
+            raise StrainCallError(rc, lib().sc_aln_error(self._h).decode())
+        return NativeReads(h, gene_seq)
 
 
 class RegionResult:
@@ -117,8 +250,16 @@ class Context:
         return StrainCallError(rc, msg.decode("utf-8", "replace") if msg else "")
 
     def submit(self, region, params):
-        """region: ingest.RegionReads.  Returns a handle."""
+        """region: ingest.RegionReads or NativeReads.  Returns a handle."""
         n = len(region)
+        if isinstance(region, NativeReads):
+            ref = region.gene_seq.encode("ascii")
+            handle = C.c_int()
+            rc = self.lib.sc_roi_submit(self.h, ref, len(ref), region._pos, region._cig, region._cig_off, region._seq, region._seq_off,
+                                        region._cn, region._mate_idx, region._mate_off, n, C.byref(params), C.byref(handle))
+            if rc != SC_OK:
+                raise self._err(rc)
+            return handle.value
         pos = (C.c_int * max(n, 1))(*region.pos)
         cn = (C.c_int * max(n, 1))(*region.copies)
         cig, cig_off = _pack(region.cigar)

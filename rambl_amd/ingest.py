@@ -290,7 +290,11 @@ class RegionReads:
 
 
 def load_mapping_reads(gene_seq, aln, mq, rl, max_ins, max_depth, gene_roi):
-    """StrainCall.cpp:480-670."""
+    """StrainCall.cpp:480-670.  With the library's own reader (aln.native) the whole function runs there
+    (sc_aln_load_reads) and the result stays in the packed arrays sc_roi_submit takes."""
+    if getattr(aln, "native", None) is not None:
+        return aln.native.load_reads(gene_seq, gene_roi_name(gene_roi), gene_roi_start_pos(gene_roi), gene_roi_end_pos(gene_roi),
+                                     mq, rl, max_ins, max_depth)
     lines = aln.view(mq, gene_roi)
     p0 = gene_roi_start_pos(gene_roi)
     p1 = gene_roi_end_pos(gene_roi)

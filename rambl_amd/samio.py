@@ -313,28 +313,47 @@ SamText.pileup_flags = _sam_pileup_flags
 
 
 class Alignments:
-    """view/mpileup provider for a mapping file (SAM text or BAM)."""
+    """view/mpileup provider for a mapping file (SAM text or BAM).
+
+    Default: the library reads and indexes the file itself (capi.NativeAln: sc_aln_*), and a window's reads never
+    become Python objects.  BAM with a `samtools` on PATH (and no SC_NATIVE_BAM=1): the reference's exact command
+    lines, parsed by the Python mirror in ingest.py.  SC_PY_INGEST=1 forces the Python mirror for SAM text / BAM
+    too (kept as the second implementation the tests compare the native one with)."""
 
     def __init__(self, path):
         self.path = path
-        # BAM: the real samtools when it is installed (exactly the reference's commands), else the
-        # native reader; SC_NATIVE_BAM=1 forces the native reader.
         import os
         self.bam = is_bam(path) and shutil.which("samtools") is not None and not os.environ.get("SC_NATIVE_BAM")
-        self.sam = None if self.bam else SamText(path, bam=is_bam(path))
+        self.native = None
+        self.sam = None
+        if not self.bam:
+            if os.environ.get("SC_PY_INGEST"):
+                self.sam = SamText(path, bam=is_bam(path))
+            else:
+                from . import capi
+                self.native = capi.NativeAln(path)
+
+    def _text(self):
+        """The Python mirror of the file (tests and tools ask for pileup / view TEXT; the product path does not)."""
+        if self.sam is None:
+            self.sam = SamText(self.path, bam=is_bam(self.path))
+        return self.sam
 
     def view(self, mq, region):
         if self.bam:   # StrainCall.cpp:496
             return _run_samtools(["view", self.path, "-q", str(mq), "-F", "1804", region])
-        return self.sam.view(mq, 1804, region)
+        return self._text().view(mq, 1804, region)
 
     def mpileup(self, mq, region):
         if self.bam:   # StrainCall.cpp:696
             return _run_samtools(["mpileup", "-q", str(mq), "-Q0", "-A", "-r", region, self.path])
-        return self.sam.mpileup(mq, region)
+        return self._text().mpileup(mq, region)
 
     def pileup_flags(self, mq, region):
         """What window_adjust extracts from the pileup (StrainCall.cpp:702-736)."""
         if self.bam:
             return flags_from_pileup_text(self.mpileup(mq, region))
+        if self.native is not None:
+            name, a0, b0 = parse_region(region)
+            return self.native.pileup_flags(mq, name, a0, b0)
         return self.sam.pileup_flags(mq, region)

@@ -7,8 +7,9 @@ StrainCall run with rambl.py's option defaults (:260-271), the per-region FASTA
 files are concatenated in .fai order.
 
 The reference fans regions out over a process pool; here one process drives one
-GPU with several regions in flight (one HIP stream each), regions are sharded
-over ranks longest-processing-time-first, nothing is exchanged while they run,
+GPU with many regions in flight (the library's level server batches their
+kernels), regions are sharded over ranks longest-processing-time-first by the
+reads that reach the graph, nothing is exchanged while they run,
 and the only collective is the final gather of FASTA bytes to rank 0 in .fai
 order (torch.distributed: RCCL over xGMI on GPUs, gloo in CPU tests).
 """
@@ -70,7 +71,7 @@ def seqtk_L(fasta_text, min_len=400):
 
 
 def prepare_region(roi, fasta, bam, opts=None, shared=None):
-    """argv -> [(window, RegionReads)] (host ingest, rows a1-a4)."""
+    """argv -> [(window, reads)] (host ingest, rows a1-a4)."""
     pa = cli.parse_cmd_line(straincall_argv(roi, fasta, bam, opts))
     if shared is None:
         return pa, cli.load_regions(pa)
@@ -84,54 +85,109 @@ def prepare_region(roi, fasta, bam, opts=None, shared=None):
     return pa, out
 
 
-_POOL_SHARED = None
+def _prepare_guarded(roi, fasta, bam, opts, shared):
+    """A region that cannot be ingested (no read covers the ROI: the reference dereferences an empty map there and
+    dies, leaving an empty <roi>.fa behind, rambl.py:159-166) must not take the other regions with it."""
+    try:
+        return prepare_region(roi, fasta, bam, opts, shared)
+    except Exception as e:                     # noqa: BLE001 - the message goes to stderr, the region yields no contig
+        return RegionFailure(roi, "%s: %s" % (type(e).__name__, e))
 
 
-def _pool_init(fasta, bam):
-    global _POOL_SHARED
-    _POOL_SHARED = (samio.Fasta(fasta), samio.read_fai(fasta + ".fai"), samio.Alignments(bam))
+class RegionFailure:
+    def __init__(self, roi, message):
+        self.roi = roi
+        self.message = message
 
 
-def _pool_prepare(job):
-    roi, fasta, bam, opts = job
-    return prepare_region(roi, fasta, bam, opts, _POOL_SHARED)
-
-
-def ingest_pool(fasta, bam, workers):
-    """Host ingest (rows a1-a4) of different regions on several cores.  Created BEFORE anything initialises
-    the GPU in this process (plain fork, no exec; the children never touch it)."""
-    import multiprocessing
+def prepared_stream(rois, fasta, bam, opts=None, workers=4, shared=None):
+    """Host ingest of the regions, in order, on `workers` threads: the library reads the alignment file once
+    (capi.NativeAln) and a window's ingest is one GIL-free call, so threads scale.  Yields (pa, [(window, reads)])
+    or a RegionFailure per region."""
+    import concurrent.futures
+    if shared is None:
+        shared = (samio.Fasta(fasta), samio.read_fai(fasta + ".fai"), samio.Alignments(bam))
     if workers <= 1:
-        return None
-    return multiprocessing.get_context("fork").Pool(workers, initializer=_pool_init, initargs=(fasta, bam))
+        for roi in rois:
+            yield _prepare_guarded(roi, fasta, bam, opts, shared)
+        return
+    with concurrent.futures.ThreadPoolExecutor(workers) as ex:
+        window = max(2 * workers, 4)
+        futs = []
+        it = iter(rois)
+        for roi in it:
+            futs.append(ex.submit(_prepare_guarded, roi, fasta, bam, opts, shared))
+            if len(futs) >= window:
+                yield futs.pop(0).result()
+        for f in futs:
+            yield f.result()
 
 
-def run_regions(ctx, prepared, streams=1, params=None):
-    """prepared: iterable of (pa, [(window, reads)]) -- a generator is consumed lazily, so the host
-    ingest of the next region overlaps the regions in flight.  Submits every window, `streams` in
-    flight, returns the FASTA text of each entry of `prepared` (in order) and the per-window stats."""
+def run_regions(ctx, prepared, streams=1, params=None, errors=None):
+    """prepared: iterable of (pa, [(window, reads)]) or RegionFailure -- a generator is consumed lazily, so the host
+    ingest of the next region overlaps the regions in flight.  Submits every window, `streams` in flight, returns the
+    FASTA text of each entry of `prepared` (in order) and the per-window stats.  A region that fails (ingest, or a
+    graph shape outside the device model) yields "" -- the empty <roi>.fa the reference pipeline would be left with --
+    and is reported in `errors` (list of (index, message)) and on stderr."""
+    import sys
     from . import capi
     texts = []
     pending = []
     stats = []
 
+    def fail(idx, what, msg):
+        sys.stderr.write("StrainCall: region %s yields no contig: %s\n" % (what, msg))
+        if errors is not None:
+            errors.append((idx, msg))
+
     def drain(k):
         while len(pending) > k:
             idx, wi, window, pa, h = pending.pop(0)
-            res = ctx.wait(h)
+            try:
+                res = ctx.wait(h)
+            except capi.StrainCallError as e:
+                fail(idx, "%s:%d-%d" % window, str(e))
+                continue
             texts[idx].append((wi, cli.format_fasta(window, res, pa.tau)))
             stats.append(res.stats)
 
-    for idx, (pa, regs) in enumerate(prepared):
+    for idx, item in enumerate(prepared):
         texts.append([])
+        if isinstance(item, RegionFailure):
+            fail(idx, item.roi, item.message)
+            continue
+        pa, regs = item
         p_ = params or capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate))
         for wi, (window, reads) in enumerate(regs):
             if len(reads) == 0:
                 continue
-            pending.append((idx, wi, window, pa, ctx.submit(reads, p_)))
+            try:
+                pending.append((idx, wi, window, pa, ctx.submit(reads, p_)))
+            except capi.StrainCallError as e:
+                fail(idx, "%s:%d-%d" % window, str(e))
+                continue
             drain(max(streams, 1))
     drain(0)
     return ["".join(t for _, t in sorted(x)) for x in texts], stats
+
+
+def region_costs(fai, aln, opts=None):
+    """Cost of a region for the longest-processing-time-first partition: the alignments that
+    reach the graph after thinning to max_depth, plus the gene length (every level costs a launch)."""
+    o = dict(RAMBL_DEFAULTS)
+    o.update(opts or {})
+    costs = []
+    for name, ln in fai:
+        glen = max(float(ingest.stoi(ln)), 1.0)
+        native = getattr(aln, "native", None)
+        if native is None:
+            costs.append(glen)
+            continue
+        n, bases = native.ref_stats(name)
+        depth = bases / glen
+        rho = min(1.0, o["max_depth"] / depth) if depth > 0 else 1.0
+        costs.append(n * rho + glen)
+    return costs
 
 
 def gather_fasta(local_texts, local_ids, n_units, dist=None, device=None):
@@ -180,25 +236,26 @@ def gather_fasta(local_texts, local_ids, n_units, dist=None, device=None):
     return "".join(out)
 
 
-def strain_call(fasta, bam, out_dir=None, prefix="rambl", opts=None, device=0, streams=4, dist=None, torch_device=None, pool=None):
+def strain_call(fasta, bam, out_dir=None, prefix="rambl", opts=None, device=0, streams=4, dist=None, torch_device=None,
+                ingest_workers=4, errors=None, ctx=None):
     """rambl.py `strain_call` for this rank's shard; rank 0 returns the concatenated
     FASTA (and writes <out_dir>/3_straincall_results/<roi>.fa + <prefix>.fa)."""
     from . import capi
     rois = roi_list(fasta + ".fai")
     fai = samio.read_fai(fasta + ".fai")
-    costs = [float(ingest.stoi(l)) for _, l in fai]
+    shared = (samio.Fasta(fasta), fai, samio.Alignments(bam))
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
-    mine = lpt_shards(costs, world)[rank]
-    if streams > 4:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(streams, 24)))   # one hardware queue per region in flight
-    if pool is not None:
-        prepared = pool.imap(_pool_prepare, [(rois[i], fasta, bam, opts) for i in mine], chunksize=1)
+    mine = lpt_shards(region_costs(fai, shared[2], opts), world)[rank]
+    prepared = prepared_stream([rois[i] for i in mine], fasta, bam, opts, ingest_workers, shared)   # ingest overlaps the regions in flight
+    errs = []
+    if ctx is not None:
+        texts, _ = run_regions(ctx, prepared, streams, errors=errs)
     else:
-        shared = (samio.Fasta(fasta), fai, samio.Alignments(bam))
-        prepared = (prepare_region(rois[i], fasta, bam, opts, shared) for i in mine)     # ingest overlaps the regions in flight
-    with capi.Context(device, streams) as ctx:
-        texts, _ = run_regions(ctx, prepared, streams)
+        with capi.Context(device, streams) as c:
+            texts, _ = run_regions(c, prepared, streams, errors=errs)
+    if errors is not None:
+        errors.extend((rois[mine[i]], m) for i, m in errs)
     if out_dir is not None:
         sc_dir = os.path.join(out_dir, "3_straincall_results")
         os.makedirs(sc_dir, exist_ok=True)
@@ -214,15 +271,16 @@ def strain_call(fasta, bam, out_dir=None, prefix="rambl", opts=None, device=0, s
 
 def main(argv=None):
     """`python -m rambl_amd.stage5 seed_otus.fasta to_seed_otus.all.bam -o WORKDIR -p PREFIX`
-    (under `torchrun --nproc-per-node N` for N GPUs): stage 5 of rambl.py + the length filter."""
+    (under `torchrun --nproc-per-node N` for N GPUs): stage 5 of rambl.py + the length filter.
+    Exit status 1 when a region failed (its <roi>.fa is empty, as under the reference pipeline)."""
     import argparse
     ap = argparse.ArgumentParser(description="rambl.py stage 5 (strain-level assembly) on MI355X")
     ap.add_argument("fasta")
     ap.add_argument("alignments", help="BAM or SAM text of the reads aligned to the seed genes")
     ap.add_argument("-o", "--out-dir", default=".")
     ap.add_argument("-p", "--prefix", default="rambl")
-    ap.add_argument("-s", "--streams", type=int, default=8, help="regions in flight per GPU")
-    ap.add_argument("-j", "--ingest-workers", type=int, default=8, help="host processes reading the alignments")
+    ap.add_argument("-s", "--streams", type=int, default=32, help="regions in flight per GPU")
+    ap.add_argument("-j", "--ingest-workers", type=int, default=4, help="host threads reading the alignments")
     for k, v in RAMBL_DEFAULTS.items():
         ap.add_argument("--" + k.replace("_", "-"), default=v, type=type(v))
     a = ap.parse_args(argv)
@@ -230,9 +288,6 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = dev = None
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.streams > 4:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(a.streams, 24)))
-    pool = ingest_pool(a.fasta, a.alignments, a.ingest_workers)      # before anything touches the GPU
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -240,17 +295,21 @@ def main(argv=None):
         dist.init_process_group("nccl", rank=int(os.environ["RANK"]), world_size=world)
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
+    errors = []
     full = strain_call(a.fasta, a.alignments, out_dir=a.out_dir, prefix=a.prefix, opts=opts, device=local,
-                       streams=a.streams, dist=dist, torch_device=dev, pool=pool)
-    if pool is not None:
-        pool.close()
+                       streams=a.streams, dist=dist, torch_device=dev, ingest_workers=a.ingest_workers, errors=errors)
     if full is not None:
         with open(os.path.join(a.out_dir, "%s.filtered.fa" % a.prefix), "w") as f:
             f.write(seqtk_L(full, 400))            # rambl.py:236-238
+    failed = len(errors)
     if world > 1:
+        import torch
+        t = torch.tensor([failed], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        failed = int(t.item())
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return 1 if failed else 0
 
 
 if __name__ == "__main__":

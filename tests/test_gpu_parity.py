@@ -351,3 +351,65 @@ def test_reference_with_ambiguity_codes(seed, tmp_path, oracle_bin):
     got = T.run_product(args, trace_file=tf)
     assert got == exp_fa
     T.compare_traces(open(tf).read(), exp_tr)
+
+
+def _sha(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def test_config3_hundred_regions_match_reference(tmp_path):
+    """BASELINE.json configs[2] at the shape SURVEY.md section 8(d) gives it: 100 seed genes (seeds 100-199, 2 000-10 000
+    reads each, 575 103 alignments) in ONE FASTA + ONE SAM, run the way scripts/rambl.py:169-201 runs stage 5 -- one
+    StrainCall per `name:1-len` of the .fai, outputs concatenated in .fai order.  Every region's FASTA must equal the
+    reference's own stdout for that region (tests/golden/config3_regions, produced by oracle/_ref in the build
+    container, 7 h of CPU), and so must the concatenation."""
+    import gzip
+    import json
+    from rambl_amd import stage5, synth
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config3_regions")
+    meta = json.load(open(os.path.join(gold, "meta.json")))
+    expected = json.loads(gzip.open(os.path.join(gold, "expected.json.gz")).read())
+    d = str(tmp_path)
+    fa, sam, _ = synth.config3(d)
+    assert _sha(fa) == meta["fasta_sha256"] and _sha(sam) == meta["sam_sha256"]
+    rois = stage5.roi_list(fa + ".fai")
+    assert rois == [r for r, _ in expected] and len(rois) == 100
+    errors = []
+    work = os.path.join(d, "work")
+    full = stage5.strain_call(fa, sam, out_dir=work, prefix="rambl", streams=32, ingest_workers=4, errors=errors)
+    assert errors == []
+    bad = [r for r, text in expected if open(os.path.join(work, "3_straincall_results", "%s.fa" % r)).read() != text]
+    assert bad == []
+    assert full == "".join(text for _, text in expected)
+    assert full.count(">") == meta["contigs"]
+
+
+@pytest.fixture(scope="module")
+def million_reads(tmp_path_factory):
+    """BASELINE.json configs[3] at its stated size: 1 000 000 x 150 bp reads, 50 strains, one 1 500 bp gene."""
+    from rambl_amd import synth
+    d = str(tmp_path_factory.mktemp("deep4m"))
+    gene = synth.make_gene(4, glen=1500, n_strains=50, n_reads=1000000, name="deep4m")
+    fa, sam = synth.write_dataset(d, [gene])
+    return fa, sam
+
+
+@pytest.mark.parametrize("depth", [800, 3000])
+def test_config4_million_reads_match_reference(depth, million_reads):
+    """The 10^6-read region through the native ingest (view, depth -> keep probability, mt19937 thinning of a million
+    candidates, duplicate collapse) and the device path: -D 800 (rambl.py's value: ~8 000 reads reach the graph) and a
+    raised -D 3000 (~30 000 reads, 3 000 read copies per level, 13 sweeps, weight rows in HBM).  FASTA equal to the
+    reference's own stdout (tests/golden/config4_full_D*, oracle/_ref in the build container; -D 3000 is the largest
+    depth the reference's quadratic edge support finishes in an hour -- tests/golden/make_golden_config4.py)."""
+    import json
+    fa, sam = million_reads
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config4_full_D%d" % depth)
+    meta = json.load(open(os.path.join(gold, "meta.json")))
+    assert _sha(fa) == meta["fasta_sha256"] and _sha(sam) == meta["sam_sha256"]
+    got = T.run_product(meta["argv"] + [fa, sam])
+    assert got == open(os.path.join(gold, "expected.fa")).read()

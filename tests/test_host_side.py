@@ -225,3 +225,92 @@ def test_native_bam_reader_gives_the_same_regions(seed, tmp_path, monkeypatch):
     for (wa, ra), (wb, rb) in zip(a, b):
         assert wa == wb and ra.gene_seq == rb.gene_seq
         assert (ra.pos, ra.cigar, ra.seq, ra.copies, ra.mates) == (rb.pos, rb.cigar, rb.seq, rb.copies, rb.mates)
+
+
+def _random_sam(rng, path, genes=("gA", "gB"), n=400, glen=400):
+    """SAM records with every CIGAR shape the ingest has a rule for: soft / hard clips, insertions and deletions at
+    and across window edges, = and X, N skips, reads hanging over both ends of a window, duplicates, mates by flag
+    and by name, repeated names, filtered flags, low mapping qualities, short reads, N bases."""
+    lines = ["@SQ\tSN:%s\tLN:%d" % (g, glen) for g in genes]
+    recs = []
+    for k in range(n):
+        g = rng.choice(genes)
+        pos = rng.randint(1, glen - 30)
+        ops = []
+        if rng.random() < 0.15:
+            ops.append((rng.randint(1, 12), "H"))
+        if rng.random() < 0.3:
+            ops.append((rng.randint(1, 15), "S"))
+        body = []
+        for _ in range(rng.randint(1, 6)):
+            body.append((rng.randint(1, 60), rng.choice("MMMM=X")))
+            r = rng.random()
+            if r < 0.25:
+                body.append((rng.randint(1, 14), "I"))
+            elif r < 0.5:
+                body.append((rng.randint(1, 9), "D"))
+            elif r < 0.55:
+                body.append((rng.randint(1, 20), "N"))
+        while body and body[-1][1] in "IDN":
+            body.pop()
+        ops += body
+        if rng.random() < 0.3:
+            ops.append((rng.randint(1, 15), "S"))
+        if rng.random() < 0.1:
+            ops.append((rng.randint(1, 12), "H"))
+        qlen = sum(l for l, o in ops if o in "MIS=X")
+        seq = "".join(rng.choice("ACGT") for _ in range(qlen))
+        if rng.random() < 0.04:
+            seq = seq[:3] + rng.choice("Nn") + seq[4:]
+        flag = rng.choice([0, 0, 0, 16, 65, 129, 81, 161, 4, 256, 512, 1024, 2048, 99, 147])
+        name = "r%d" % rng.randint(0, n // 2)
+        if rng.random() < 0.1:
+            name += rng.choice(["/1", "/2"])
+        mapq = rng.choice([0, 1, 3, 9, 10, 12, 30, 42, 60])
+        recs.append((g, pos, "\t".join([name, str(flag), g, str(pos), str(mapq), "".join("%d%s" % x for x in ops), "*", "0", "0", seq,
+                                        "I" * len(seq)])))
+        if rng.random() < 0.2:      # an exact duplicate under another name
+            f = recs[-1][2].split("\t")
+            f[0] = "d%d" % k
+            recs.append((g, pos, "\t".join(f)))
+    recs.sort(key=lambda r: (r[0], r[1]))
+    with open(path, "w") as f:
+        f.write("\n".join(lines + [r[2] for r in recs]) + "\n")
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_native_ingest_equals_python_mirror(seed, tmp_path):
+    """sc_aln_* (C++, the product's reader) against the Python mirror of StrainCall.cpp:480-736 on records with every
+    CIGAR shape, over many windows and option values: reads, copies, mates, depth thinning, pileup flags."""
+    from rambl_amd import capi, samio
+    rng = random.Random(1000 + seed)
+    sam = str(tmp_path / "x.sam")
+    _random_sam(rng, sam)
+    nat = capi.NativeAln(sam)
+    py = samio.SamText(sam)
+
+    class PyAln:
+        native = None
+        view = staticmethod(lambda mq, region: py.view(mq, 1804, region))
+    n_checked = 0
+    for _ in range(40):
+        g = rng.choice(["gA", "gB"])
+        p0 = rng.randint(1, 300)
+        p1 = rng.randint(p0 + 5, 400)
+        mq = rng.choice([0, 3, 10])
+        rl = rng.choice([0, 20, 70])
+        max_ins = rng.choice([3, 10, 13])
+        max_depth = rng.choice([2, 10, 800])
+        roi = "%s:%d-%d" % (g, p0, p1)
+        assert nat.pileup_flags(mq, g, p0, p1) == py.pileup_flags(mq, roi)
+        try:
+            exp = ingest.load_mapping_reads("", PyAln, mq, rl, max_ins, max_depth, roi)
+        except (ValueError, IndexError):
+            with pytest.raises(capi.StrainCallError):
+                nat.load_reads("", g, p0, p1, mq, rl, max_ins, max_depth)
+            continue
+        got = nat.load_reads("", g, p0, p1, mq, rl, max_ins, max_depth)
+        assert (got.pos, got.cigar, got.seq, got.copies, got.mates) == (exp.pos, exp.cigar, exp.seq, exp.copies, exp.mates), roi
+        assert got.n_input == len(py.view(mq, 1804, roi))
+        n_checked += len(exp)
+    assert n_checked > 200

@@ -55,3 +55,59 @@ def test_gather_world2_gloo(tmp_path):
                            "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)], env=env,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     assert (tmp_path / "ok").read_text() == "ok"
+
+
+def _two_gene_dataset(d):
+    from rambl_amd import synth
+    genes = [synth.make_gene(700, glen=300, n_strains=2, n_reads=150, rlen=110, name="full"),
+             synth.make_gene(701, glen=300, n_strains=1, n_reads=0, rlen=110, name="bare"),
+             synth.make_gene(702, glen=300, n_strains=1, n_reads=1200, rlen=110, name="deep")]
+    return synth.write_dataset(d, genes)
+
+
+def test_region_costs_follow_reads_after_thinning(tmp_path):
+    """LPT cost = alignments that reach the graph after thinning to -D, plus the gene length."""
+    from rambl_amd import samio
+    fa, sam = _two_gene_dataset(str(tmp_path))
+    fai = samio.read_fai(fa + ".fai")
+    aln = samio.Alignments(sam)
+    full, bare, deep = stage5.region_costs(fai, aln, {"max_depth": 100})
+    assert bare == 300.0                                   # no alignment: only the levels
+    assert abs(full - (150 + 300)) < 1                     # depth 55 < 100: every read counts
+    assert 300 + 250 < deep < 300 + 330                    # depth 440 thinned to 100: ~1200 * 100 / 440 reads
+    assert stage5.lpt_shards([full, bare, deep], 2) == [[2], [0, 1]] or stage5.lpt_shards([full, bare, deep], 2) == [[0, 1], [2]][::-1]
+
+
+def test_failing_region_does_not_take_the_others_down(tmp_path, capsys):
+    """rambl.py ignores StrainCall's exit status (rambl.py:159-166): a region that cannot be assembled leaves an empty
+    <roi>.fa and the others are still concatenated.  Here: an ROI no read covers (ingest raises), and a region the
+    device refuses -- with a stand-in context, this test runs without a GPU."""
+    from rambl_amd import capi
+    fa, sam = _two_gene_dataset(str(tmp_path))
+    rois = stage5.roi_list(fa + ".fai")
+    prepared = list(stage5.prepared_stream(rois, fa, sam, None, workers=2))
+    assert isinstance(prepared[1], stage5.RegionFailure) and prepared[1].roi == "bare:1-300"
+    assert not isinstance(prepared[0], stage5.RegionFailure) and len(prepared[0][1][0][1]) > 0
+
+    class Res:
+        seqs, abundance, stats = ["ACGT"], [1.0], {}
+
+    class FakeCtx:
+        def __init__(self):
+            self.n = 0
+
+        def submit(self, reads, params):
+            self.n += 1
+            return self.n
+
+        def wait(self, h):
+            if h == 2:
+                raise capi.StrainCallError(-4, "more than 16 distinct symbols")
+            return Res()
+
+    errors = []
+    texts, stats = stage5.run_regions(FakeCtx(), prepared, streams=2, params=object(), errors=errors)
+    assert texts[0].startswith(">contigfull") and texts[1] == "" and texts[2] == ""
+    assert [i for i, _ in errors] == [1, 2]
+    err = capsys.readouterr().err
+    assert "bare:1-300" in err and "deep" in err and "SC_ERR_UNSUPPORTED" in err
