@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """Benchmark of the StrainCall hot path on MI355X.
 
-A step = one pass of the path (graph build + level walk with its HIP kernels +
-read_assign) over one region: BASELINE.json configs[1], 10 000 synthetic 150 bp
-reads against one 1 500 bp gene (seed 21).  With N > 1 ranks every rank runs a
-region of the same shape and seed (weak scaling), nothing is exchanged
-while regions run, and the step ends with the RCCL gather of the FASTA bytes to
-rank 0.  Prints ONE JSON line on rank 0.
+N = 1 (the headline, BASELINE.json configs[1]): a step = one pass of the path (graph build + level walk with its HIP
+kernels + read_assign) over one region, 10 000 synthetic 150 bp reads against one 1 500 bp gene (seed 21).
+N > 1 (BASELINE.json configs[2], what north_star shards over the GPUs of a node): a step = the 100-seed-gene set
+(seeds 100-199, 575 103 alignments) partitioned longest-processing-time-first over the ranks, every rank with many
+regions in flight on its GPU, no exchange while regions run, one gather of the FASTA bytes to rank 0 at the end
+(RCCL).  Total work is fixed: strong scaling.
+
+`python bench.py --gpus N` starts the N ranks itself (children are spawned before anything touches a GPU, the parent
+only relays rank 0's line); under `torch.distributed.run` the ranks come from the environment.  Prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -21,11 +25,25 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_READ = 320      # L + 16 + 4*ops + L for 150 bp, one-op reads
 HBM_PEAK = 8.0e12             # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
+RAMBL_OPTS = "-q 0 -D 800 -I 13 -l 70 -t 0.02 -d 0.02 -w 5000"
+
+
+def cpu_budget():
+    """CPUs this process may use (the GPU box hands out a cgroup share of its host)."""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_baseline(data_dir, fasta, sam, roi):
-    """Reference (oracle/_ref, kind "reference") or the C oracle (kind "port")
-    on a bounded interior sample of the same data set, one core."""
+    """The reference itself (oracle/_ref, kind "reference") or the C oracle (kind "port") on a bounded interior sample
+    of the bench data set: one process on one core, then one process per available core at once -- rambl.py's
+    Pool(cores) over regions (scripts/rambl.py:190-194)."""
     tools = os.path.join(ROOT, "oracle", "tools")
     ref = os.path.join(ROOT, "oracle", "_ref", "StrainCall_ref")
     port = os.path.join(ROOT, "oracle", "straincall_oracle")
@@ -37,16 +55,95 @@ def cpu_baseline(data_dir, fasta, sam, roi):
         exe, kind = port, "port"
     env = dict(os.environ)
     env["PATH"] = tools + os.pathsep + env.get("PATH", "")
-    env["TMPDIR"] = data_dir
-    args = ["-r", roi, "-q", "0", "-D", "800", "-I", "13", "-l", "70", "-t", "0.02", "-d", "0.02", "-w", "5000", fasta, sam]
+    args = ["-r", roi] + RAMBL_OPTS.split() + [fasta, sam]
     n_reads = len(subprocess.run([os.path.join(tools, "samtools"), "view", sam, "-q", "0", "-F", "1804", roi],
                                  stdout=subprocess.PIPE, env=env).stdout.splitlines())
+
+    def run(k):
+        cwd = os.path.join(data_dir, "cpu%d" % k)      # the reference's temp files collide in a shared directory
+        os.makedirs(cwd, exist_ok=True)
+        e = dict(env, TMPDIR=cwd)
+        return subprocess.Popen([exe] + args, cwd=cwd, env=e, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+
     t0 = time.time()
-    p = subprocess.run([exe] + args, cwd=data_dir, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    p = run(0)
+    fasta_text = p.communicate()[0].decode()
     dt = time.time() - t0
+    cores = cpu_budget()
+    t0 = time.time()
+    ps = [run(1 + k) for k in range(cores)]
+    outs = [q.communicate()[0].decode() for q in ps]
+    dt_all = time.time() - t0
     return dict(value=n_reads / dt, unit="reads/s", cores=1, kind=kind, seconds=dt, sample_reads=n_reads,
                 sample="%s of the bench data set (reads cropped to the window), -O2 build, rambl.py options" % roi,
-                fasta=p.stdout.decode()), args
+                all_cores={"cores": cores, "processes": cores, "value": cores * n_reads / dt_all, "unit": "reads/s", "seconds": dt_all,
+                           "same_output": all(o == fasta_text for o in outs),
+                           "note": "one reference process per available core on the same sample, as rambl.py's Pool(cores) runs regions"},
+                fasta=fasta_text), args
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks (before this process touches any GPU) and
+    relay rank 0's line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(rcs)
+
+
+def roofline(all_stats, steps, world):
+    k_ms = sum(s["sampler_kernel_ms"] for s in all_stats)
+    k_n = sum(s["sampler_launches"] for s in all_stats)
+    k_copies = sum(s["sampler_read_copies"] for s in all_stats)
+    draws = sum(s["draws"] for s in all_stats)
+    timing = "HIP events around every sampler launch, on the stream it is launched on"
+    if not k_ms:
+        # many regions in flight: levels of several regions leave as one grid, so the duration of one region's sampler level
+        # is the kernel's own 100 MHz wall clock from its start to its completion stamp
+        k_ms = sum(s["sampler_level_ticks"] for s in all_stats) / 1e5
+        timing = "the level kernels' own wall clock (s_memrealtime), start of the workgroup to its completion stamp"
+    avg_ms = k_ms / max(k_n, 1)
+    achieved = (ALG_BYTES_PER_READ * k_copies / max(k_n, 1)) / (avg_ms * 1e-3) if k_n and k_ms else 0.0
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
+    if os.path.exists(pmc) and world == 1:
+        # HBM bytes per sampler launch from the committed rocprofv3 --pmc passes of this command
+        traffic = json.load(open(pmc)).get("sample_traffic_bytes_per_launch")
+        traffic_src = "profiles/r02/pmc_summary.json (separate FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes)"
+    return {"bound": "hbm", "kernel": "sc::k_level_sample<NB,L> (one sampler level: read log-likelihood update, weight rows, urn chain)",
+            "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": ALG_BYTES_PER_READ * k_copies / max(k_n, 1),
+            "avg_launch_ms": avg_ms, "launch_timing": timing, "launches_per_step": k_n / max(steps, 1),
+            "draws_per_s_per_region": draws / (k_ms * 1e-3) if k_ms else 0.0,
+            "note": "a latency-bound serial chain working out of LDS: the HBM fraction is tiny by construction (SURVEY.md section 8(d)); "
+                    "chain_cycles_per_draw is the rate that matters"}
+
+
+def breakdown(all_stats, steps):
+    draws = sum(s["draws"] for s in all_stats)
+    k_n = sum(s["sampler_launches"] for s in all_stats)
+    return {"graph_host": sum(s["graph_ms"] for s in all_stats) / steps,
+            "level_walk": sum(s["cluster_ms"] for s in all_stats) / steps,
+            "level_kernels": sum(s["level_kernel_ticks"] for s in all_stats) / 1e5 / steps,
+            "urn_chains": sum(s["chain_wall_ticks"] for s in all_stats) / 1e5 / steps,
+            "levels": sum(s["level_launches"] for s in all_stats) / steps,
+            "draws": draws / steps,
+            "slow_tier_draws": sum(s["slow_draws"] for s in all_stats) / steps,
+            "exact_draws": sum(s["exact_draws"] for s in all_stats) / steps,
+            "chain_passes": sum(s["chain_passes"] for s in all_stats) / steps,
+            "chain_cycles_per_draw": sum(s["chain_cycles"] for s in all_stats) / max(draws, 1),
+            "chain_ns_per_draw": 10.0 * sum(s["chain_wall_ticks"] for s in all_stats) / max(draws, 1),
+            "avg_candidates_per_sampler_launch": sum(s["sampler_strains"] for s in all_stats) / max(k_n, 1)}
 
 
 def main():
@@ -59,13 +156,13 @@ def main():
     ap.add_argument("--strains", type=int, default=3)
     ap.add_argument("--sample-roi", default="700-860")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--regions", type=int, default=1, help="regions per GPU and step (1 = BASELINE configs[1]; >1 = configs[2]-style batch)")
-    ap.add_argument("--streams", type=int, default=0, help="regions in flight per GPU (default: min(regions, 16))")
+    ap.add_argument("--no-set", action="store_true", help="N = 1: skip the 100-region leg (regions_in_flight)")
+    ap.add_argument("--streams", type=int, default=128, help="regions in flight per GPU on the 100-region set")
     a = ap.parse_args()
 
-    streams = a.streams if a.streams > 0 else min(a.regions, 16)
-    # one hardware queue per region in flight (the in-flight leg below uses 16); must precede HIP initialisation
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(max(streams, 16), 24)))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,124 +177,168 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
 
-    from rambl_amd import capi, cli, stage5, synth
-    d = tempfile.mkdtemp(prefix="scbench_%d_" % rank)
-    prepared = []
-    for k in range(a.regions):
-        seed = 21 + k                                    # the same regions on every rank: per-GPU work is fixed (weak scaling)
-        gene = synth.make_gene(seed, glen=a.glen, n_strains=a.strains, n_reads=a.reads, name="gene%d" % seed)
-        fasta, sam = synth.write_dataset(os.path.join(d, "r%d" % k), [gene])
-        roi = "%s:1-%d" % (gene["name"], a.glen)
-        pa = cli.parse_cmd_line(stage5.straincall_argv(roi, fasta, sam))
-        prepared.append((pa, cli.load_regions(pa)))      # host ingest, outside the timed region
-    pa, regions = prepared[0]
-    fasta, sam = pa.gene_file, pa.mapping_file
-    gene = {"name": "gene21"}
-    params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate), want_timing=True)
-    ctx = capi.Context(local, streams)
-
-    def step():
-        texts, stats = stage5.run_regions(ctx, prepared, streams, params)
-        full = stage5.gather_fasta(["".join(texts)], [rank], world, dist if world > 1 else None, dev)
-        return full, stats
+    from rambl_amd import capi, cli, samio, stage5, synth
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(dt):
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
+
+    def region_set(dirname):
+        """The configs[2] set: 100 seed genes in one FASTA + one SAM, ingested (rows a1-a4, native) for this rank's shard."""
+        fa, sam = os.path.join(dirname, "seed_otus.fasta"), os.path.join(dirname, "reads.sam")
+        if rank == 0 and not os.path.exists(sam + ".done"):
+            synth.config3(dirname)
+            open(sam + ".done", "w").write("ok")
+        if world > 1:
+            dist.barrier()
+        fai = samio.read_fai(fa + ".fai")
+        rois = stage5.roi_list(fa + ".fai")
+        t0 = time.time()
+        aln = samio.Alignments(sam)
+        shared = (samio.Fasta(fa), fai, aln)
+        mine = stage5.lpt_shards(stage5.region_costs(fai, aln), world)[rank]
+        prepared = list(stage5.prepared_stream([rois[i] for i in mine], fa, sam, None, 4, shared))
+        ingest_s = time.time() - t0
+        n_in = sum(r.n_input for _, regs in prepared for _, r in regs)
+        n_graph = sum(sum(r.copies) for _, regs in prepared for _, r in regs)
+        return rois, mine, prepared, ingest_s, n_in, n_graph, aln.native.records()
+
+    if world > 1:
+        # ---- configs[2]: the 100-region set sharded over the ranks
+        d = os.path.join(tempfile.gettempdir(), "scbench_set_%s" % os.environ.get("MASTER_PORT", "0"))
+        os.makedirs(d, exist_ok=True)
+        rois, mine, prepared, ingest_s, n_in, n_graph, n_total = region_set(d)
+        streams = min(a.streams, max(len(mine), 1))
+        ctx = capi.Context(local, streams)
+
+        def step():
+            texts, stats = stage5.run_regions(ctx, prepared, streams)
+            return stage5.gather_fasta(texts, mine, len(rois), dist, dev), stats
+
+        for _ in range(a.warmup):
+            step()
+        fence()
+        t0 = time.time()
+        all_stats, fasta_out = [], None
+        for _ in range(a.steps):
+            fasta_out, st = step()
+            all_stats += st
+        fence()
+        dt = max_over_ranks(time.time() - t0)
+        ingest_max = max_over_ranks(ingest_s)
+        ctx.close()
+        if rank == 0:
+            line = {"metric": "reads/sec into POA (150bp, ~1.5k-node graph)", "value": n_total * a.steps / dt, "unit": "reads/s",
+                    "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+                    "ms_per_step_with_ingest": 1e3 * (dt / a.steps + ingest_max),
+                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                    "config": {"workload": "configs[2]: 100 seed genes x 1500 bp (seeds 100-199), 2000-10000 x 150bp reads each, %d alignments "
+                                           "in one FASTA + one SAM, rambl.py options (%s)" % (n_total, RAMBL_OPTS),
+                               "regions": len(rois), "regions_in_flight_per_gpu": streams,
+                               "parallelism": "regions sharded LPT over %d ranks, no exchange while they run, FASTA gather over %s" % (
+                                   world, "RCCL" if backend == "nccl" else backend)},
+                    "rank0": {"regions": len(mine), "alignments": n_in, "read_copies_after_ingest": n_graph,
+                              "roofline": roofline(all_stats, a.steps, world), "breakdown_ms_per_step_summed_over_regions": breakdown(all_stats, a.steps)},
+                    "contigs": fasta_out.count(">") if fasta_out else 0}
+            line["roofline"] = line["rank0"].pop("roofline")
+            print(json.dumps(line), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    # ---- N = 1, configs[1]: one region
+    d = tempfile.mkdtemp(prefix="scbench_")
+    gene = synth.make_gene(21, glen=a.glen, n_strains=a.strains, n_reads=a.reads, name="gene21")
+    fasta, sam = synth.write_dataset(os.path.join(d, "r0"), [gene])
+    roi = "gene21:1-%d" % a.glen
+    argv = stage5.straincall_argv(roi, fasta, sam)
+    pa = cli.parse_cmd_line(argv)
+    regions = cli.load_regions(pa)                       # host ingest (rows a1-a4), outside the headline's timed region
+    n_graph = sum(sum(r.copies) for _, r in regions)
+    params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate), want_timing=True)
+    ctx = capi.Context(local, 1)
+
+    def step(prepared):
+        texts, stats = stage5.run_regions(ctx, prepared, 1, params)
+        return "".join(texts), stats
+
     for _ in range(a.warmup):
-        step()
+        step([(pa, regions)])
     fence()
     t0 = time.time()
-    all_stats = []
-    fasta_out = None
+    all_stats, fasta_out = [], None
     for _ in range(a.steps):
-        fasta_out, st = step()
+        fasta_out, st = step([(pa, regions)])
         all_stats += st
     fence()
     dt = time.time() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)   # MAX over ranks
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    # the same steps with rows a1-a4 inside the clock: open + index the SAM, scan windows, view / crop / thin / dedup
+    fence()
+    t0 = time.time()
+    for _ in range(a.steps):
+        pa_i = cli.parse_cmd_line(argv)
+        with_ingest, _ = step([(pa_i, cli.load_regions(pa_i))])
+    fence()
+    dt_ingest = time.time() - t0
     ctx.close()
 
-    if rank == 0:
-        total_reads = a.reads * a.regions * a.steps * world
-        k_ms = sum(s["sampler_kernel_ms"] for s in all_stats)
-        k_n = sum(s["sampler_launches"] for s in all_stats)
-        k_copies = sum(s["sampler_read_copies"] for s in all_stats)
-        draws = sum(s["draws"] for s in all_stats)
-        avg_ms = k_ms / max(k_n, 1)
-        achieved = (ALG_BYTES_PER_READ * k_copies / max(k_n, 1)) / (avg_ms * 1e-3) if k_n else 0.0
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
-        if os.path.exists(pmc) and world == 1:
-            # HBM bytes per SAMPLE launch from the committed rocprofv3 --pmc passes of this command
-            traffic = json.load(open(pmc)).get("sample_traffic_bytes_per_launch")
-            traffic_src = "profiles/r01/pmc_summary.json (separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled)"
-        line = {
-            "metric": "reads/sec into POA (150bp, ~1.5k-node graph)", "value": total_reads / dt, "unit": "reads/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+    line = {"metric": "reads/sec into POA (150bp, ~1.5k-node graph)", "value": a.reads * a.steps / dt, "unit": "reads/s",
+            "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "ms_per_step_with_ingest": 1e3 * dt_ingest / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d x 150bp reads vs one %dbp gene, %d strains, seed 21, "
-                                   "rambl.py options (-q 0 -D 800 -I 13 -l 70 -t 0.02 -d 0.02 -w 5000)" % (a.reads, a.glen, a.strains),
-                       "regions_per_gpu": a.regions, "regions_in_flight_per_gpu": streams,
-                       "parallelism": "region-sharded x%d, FASTA gather over RCCL" % world},
-            "roofline": {"bound": "hbm", "kernel": "sc::k_chain_w<NB,L> (urn sampler of one level)", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_READ * k_copies / max(k_n, 1),
-                         "avg_launch_ms": avg_ms, "launches_per_step": k_n / max(a.steps, 1),
-                         "draws_per_s_per_region": draws / (k_ms * 1e-3) if k_ms else 0.0},
-            "breakdown_ms_per_step": {"graph_host": sum(s["graph_ms"] for s in all_stats) / a.steps,
-                                      "level_walk": sum(s["cluster_ms"] for s in all_stats) / a.steps,
-                                      "sampler_kernels": k_ms / a.steps,
-                                      "draws": draws / a.steps,
-                                      "slow_tier_draws": sum(s["slow_draws"] for s in all_stats) / a.steps,
-                                      "exact_draws": sum(s["exact_draws"] for s in all_stats) / a.steps,
-                                      "chain_passes": sum(s["chain_passes"] for s in all_stats) / a.steps,
-                                      "chain_cycles_per_draw": sum(s["chain_cycles"] for s in all_stats) / max(draws, 1),
-                                      "chain_ns_per_draw": 10.0 * sum(s["chain_wall_ticks"] for s in all_stats) / max(draws, 1),
-                                      "avg_candidates_per_sampler_launch": sum(s["sampler_strains"] for s in all_stats) / max(k_n, 1)},
+            "config": {"workload": "configs[1]: %d x 150bp reads vs one %dbp gene, %d strains, seed 21, rambl.py options (%s)" % (
+                a.reads, a.glen, a.strains, RAMBL_OPTS),
+                "regions_per_gpu": 1, "regions_in_flight_per_gpu": 1, "parallelism": "one region, one GPU (a single region does not shard: replicas only)",
+                "input_reads": a.reads, "read_copies_after_ingest": n_graph},
+            "roofline": roofline(all_stats, a.steps, 1),
+            "breakdown_ms_per_step": breakdown(all_stats, a.steps),
             "contigs": fasta_out.count(">") if fasta_out else 0,
-        }
-        if not a.no_cpu and a.regions == 1:
-            cb, cargs = cpu_baseline(d, fasta, sam, "%s:%s" % (gene["name"], a.sample_roi))
-            ref_fa = cb.pop("fasta")
-            # the same sample on the GPU, for a like-for-like ratio and a parity check of the sample
-            pa2 = cli.parse_cmd_line(cargs)
-            regs2 = cli.load_regions(pa2)
-            ctx2 = capi.Context(local, 1)
-            t1 = time.time()
-            got = "".join(cli.format_fasta(w, ctx2.run(r, params), pa2.tau) for w, r in regs2)
-            dt2 = time.time() - t1
-            ctx2.close()
-            cb["gpu_same_sample_reads_per_s"] = cb["sample_reads"] / dt2
-            cb["gpu_same_sample_matches_cpu_fasta"] = (got == ref_fa)
-            line["cpu_baseline"] = cb
-            if world == 1:
-                # the production shape (rambl.py stage 5 hands over one region per seed gene): 16 regions of the
-                # same size in flight on this GPU, separate streams; reported beside the headline, not as it
-                prep16 = []
-                for k in range(16):
-                    g16 = synth.make_gene(21 + k, glen=a.glen, n_strains=a.strains, n_reads=a.reads, name="gene%d" % (21 + k))
-                    fa16, sam16 = synth.write_dataset(os.path.join(d, "f%d" % k), [g16])
-                    pa16 = cli.parse_cmd_line(stage5.straincall_argv("%s:1-%d" % (g16["name"], a.glen), fa16, sam16))
-                    prep16.append((pa16, cli.load_regions(pa16)))
-                ctx16 = capi.Context(local, 16)
-                params16 = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate))   # no per-launch events
-                stage5.run_regions(ctx16, prep16, 16, params16)
-                t1 = time.time()
-                stage5.run_regions(ctx16, prep16, 16, params16)
-                dt16 = time.time() - t1
-                ctx16.close()
-                line["regions_in_flight"] = {"regions": 16, "reads": 16 * a.reads, "value": 16 * a.reads / dt16, "unit": "reads/s",
-                                             "seconds": dt16, "note": "16 regions of the configs[1] shape (seeds 21-36) on 16 streams of one GPU"}
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+            "with_ingest_matches": with_ingest == fasta_out}
+    if not a.no_cpu:
+        cb, cargs = cpu_baseline(d, fasta, sam, "gene21:%s" % a.sample_roi)
+        ref_fa = cb.pop("fasta")
+        # the same sample on the GPU (ingest inside the clock, as the CPU figure has it): the like-for-like ratio
+        ctx2 = capi.Context(local, 1)
+        pa2 = cli.parse_cmd_line(cargs)
+        stage5.run_regions(ctx2, [(pa2, cli.load_regions(pa2))], 1)
+        t1 = time.time()
+        pa2 = cli.parse_cmd_line(cargs)
+        got, _ = stage5.run_regions(ctx2, [(pa2, cli.load_regions(pa2))], 1)
+        dt2 = time.time() - t1
+        ctx2.close()
+        cb["gpu_same_sample_reads_per_s"] = cb["sample_reads"] / dt2
+        cb["gpu_same_sample_matches_cpu_fasta"] = ("".join(got) == ref_fa)
+        cb["gpu_over_cpu_same_sample_one_core"] = cb["gpu_same_sample_reads_per_s"] / cb["value"]
+        cb["gpu_over_cpu_same_sample_all_cores"] = cb["gpu_same_sample_reads_per_s"] / cb["all_cores"]["value"]
+        cb["comparison"] = "the same sample on both sides, ingest included on both: gpu_same_sample_reads_per_s vs value (1 core) and vs all_cores.value"
+        line["cpu_baseline"] = cb
+    if not a.no_set:
+        # the production shape (rambl.py stage 5 hands over one region per seed gene): the configs[2] set on this GPU with many
+        # regions in flight -- the N = 1 point of the sharded series that `--gpus N` runs; reported beside the headline, not as it
+        ds = os.path.join(d, "set")
+        os.makedirs(ds, exist_ok=True)
+        rois, mine, prepared, ingest_s, n_in, n_graph_set, n_total = region_set(ds)
+        streams = min(a.streams, len(mine))
+        ctxs = capi.Context(local, streams)
+        stage5.run_regions(ctxs, prepared[:streams], streams)
+        t1 = time.time()
+        texts, st_set = stage5.run_regions(ctxs, prepared, streams)
+        dts = time.time() - t1
+        ctxs.close()
+        line["regions_in_flight"] = {"workload": "configs[2] set on one GPU: 100 regions, %d alignments" % n_total, "regions": len(rois),
+                                     "in_flight": streams, "value": n_total / dts, "unit": "reads/s", "seconds": dts,
+                                     "ingest_seconds": ingest_s, "value_with_ingest": n_total / (dts + ingest_s),
+                                     "read_copies_after_ingest": n_graph_set, "contigs": "".join(texts).count(">"),
+                                     "avg_sampler_level_ms": sum(s["chain_wall_ticks"] for s in st_set) / 1e5 / max(sum(s["sampler_launches"] for s in st_set), 1)}
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

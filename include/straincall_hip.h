@@ -72,6 +72,7 @@ typedef struct sc_stats {
     long chain_cycles;        /* shader cycles spent inside the urn chains */
     long chain_wall_ticks;    /* the same in 100 MHz ticks */
     long level_kernel_ticks;  /* 100 MHz ticks inside the level kernels (start of the kernel to its completion stamp) */
+    long sampler_level_ticks; /* the part of it spent in sampler levels (one workgroup of k_level_sample each) */
     long xcd_levels[8];       /* level kernels that ran on each of the 8 XCDs (HW_REG_XCC_ID) */
     long msa_calls;
     int n_nodes, n_levels, n_unique_reads;

@@ -617,7 +617,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     std::vector<std::pair<int, int>> pending_copies;     // (src slot, dst slot) for the next launch
     double sampler_ms = 0;
     long sampler_launches = 0, level_launches = 0, draws = 0, exact = 0, slow = 0, sampler_copies = 0, sampler_strains = 0, passes = 0;
-    unsigned long long chain_cycles = 0, chain_wall = 0, level_ticks = 0;
+    unsigned long long chain_cycles = 0, chain_wall = 0, level_ticks = 0, sampler_ticks = 0;
 
     double t_last_done = now_ms();
     FILE* level_log = getenv("SC_LEVEL_LOG") ? fopen((std::string(getenv("SC_LEVEL_LOG")) + "." + std::to_string(slot)).c_str(), "a") : nullptr;   // diagnostics only
@@ -673,6 +673,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             chain_cycles += Rh->chain_cycles; chain_wall += Rh->chain_wall;
         }
         level_ticks += Rh->level_wall;
+        if (chain) sampler_ticks += Rh->level_wall;
         if (level_log) {
             const double t_done = now_ms();
             fprintf(level_log, "h %d mode %d S %d Q %d n %d level_us %.1f chain_us %.1f cyc %llu passes %llu slow %llu xcc %d ncopy %d multi %d "
@@ -925,6 +926,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     job.stats.chain_wall_ticks = (long)chain_wall;
     job.stats.sampler_strains = sampler_strains;
     job.stats.level_kernel_ticks = (long)level_ticks;
+    job.stats.sampler_level_ticks = (long)sampler_ticks;
 }
 
 void Worker::process(Job& job) {
