@@ -39,6 +39,7 @@ void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node
 bool level_wants_grid(const JobDev& job, const LevelHdr& h);
 int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* Pd);
 int level_kind(const LevelHdr& h);
+int level_table_capacity();
 void launch_level_batch(hipStream_t st, int kind, const LevelBatch& b, int n);
 void launch_msa(hipStream_t st, const MsaDev& d);
 void launch_thread(hipStream_t st, const ThreadDev& d, int* pool_sorted);
@@ -128,16 +129,24 @@ struct Job {
 };
 
 typedef long double ld;               // the reference keeps abundances and counts in DoubleL = long double (x87 80-bit)
-struct HStrain {                      // host bookkeeping of one candidate (Strain, PartialOrderGraph.hpp:362-402)
-    ld sub[KK];                       // sub_count over the symbol table
+// Host bookkeeping of one candidate (Strain, PartialOrderGraph.hpp:362-402).  The substitution model is the bulky
+// part and lives in a pool: a candidate that survives a level keeps its model where it is (no copy when the candidate
+// lists are filtered, sorted or extended), only the second and later children of a parent get a copy.
+struct Model {
+    ld sub[KK];                       // sub_count over the symbol table (stride KMAX)
     ld comp[6]; ld Z;
+    ld lsub[KK];                      // logl(sub), valid where `stale` is clear
+    double lpc[KK];                   // log sub(a,b) - log comp(a) as the device reads it; rows in `dirty` are stale
+    uint16_t stale[KMAX];             // per row: entries whose count changed since lsub was formed
+    unsigned dirty;
+};
+struct HStrain {
     ld abundance;
+    int model;                        // index into the model pool
     int slot;                         // row of the device read_loglik matrix
     int tail;                         // path arena index
     int node;                         // last node of the path
     uint64_t hash; int seqlen;        // rolling hash / length of strain_seq()
-    double lpc[KK];                   // cached log sub(a,b) - log comp(a); rows in `dirty` are stale
-    unsigned dirty;
 };
 struct PathRec { int node, parent; };
 
@@ -395,16 +404,17 @@ int Worker::msa_device(const std::vector<std::string>& seqs, std::vector<std::st
 void Worker::thread_device(const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cig,
                            ThreadTables& T) {
     const int glen = (int)G.size(), n = (int)R.size();
-    // symbol table of the window: A C G T first, then every other byte that occurs, in byte order
+    // symbol table of the READS: A C G T first, then every other byte that occurs in a read, in byte order.  A base of the
+    // gene that no read carries (an IUPAC code of a 16S reference) keeps the code 0xFF: no read base equals it, so every
+    // read base aligned there lands in a sibling class, as `G[i]==r[j]` decides in the reference (PartialOrderGraph.cpp:133)
     bool present[256] = {false};
-    for (unsigned char c : G) present[c] = true;
     for (const auto& r : R) for (unsigned char c : r.seq) present[c] = true;
     std::memset(T.lut, 0xFF, sizeof T.lut);
     T.sym.clear();
     for (char c : {'A', 'C', 'G', 'T'}) { T.lut[(unsigned char)c] = (uint8_t)T.sym.size(); T.sym.push_back(c); }
     for (int c = 0; c < 256; c++)
         if (present[c] && T.lut[c] == 0xFF) {
-            if (T.sym.size() >= 8) throw ScError(SC_ERR_UNSUPPORTED, "more than 8 distinct symbols in reads and reference");
+            if (T.sym.size() >= 8) throw ScError(SC_ERR_UNSUPPORTED, "more than 8 distinct symbols in the reads");
             T.lut[c] = (uint8_t)T.sym.size(); T.sym.push_back((char)c);
         }
     std::vector<int> pos(n), seq_off(n + 1, 0), cig_off(n + 1, 0), cig_len;
@@ -464,7 +474,7 @@ void Worker::thread_device(const std::string& G, const std::vector<AlignedRead>&
     fix(T.minrid); fix(T.smin); fix(T.emin); fix(T.tmin);
 }
 
-static void recount(HStrain& s) {                                         // Strain.cpp:115-124
+static void recount(Model& s) {                                           // Strain.cpp:115-124
     s.Z = 0;
     for (int i = 0; i < 6; i++) {
         s.comp[i] = 0;
@@ -560,6 +570,11 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
 
     // ---- level walk
     std::vector<HStrain> level_strains, sub_strains;
+    std::vector<Model> models;                                           // pool; free entries in free_models
+    std::vector<int> free_models;
+    auto model_new = [&]() { if (!free_models.empty()) { const int m = free_models.back(); free_models.pop_back(); return m; }
+                             models.emplace_back(); return (int)models.size() - 1; };
+    auto drop = [&](const HStrain& s, std::vector<int>& free_slots_) { free_slots_.push_back(s.slot); free_models.push_back(s.model); };
     std::vector<PathRec> arena;
     std::vector<int> free_slots;
     for (int i = MAXS - 1; i >= 0; i--) free_slots.push_back(i);
@@ -605,10 +620,13 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
 
     {   // level_strains.push_back(Strain(100,e)), NonparametricClustering.cpp:281; Strain.cpp:41-71
         HStrain s{};
-        for (int i = 0; i < KK; i++) s.sub[i] = 0;
-        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) s.sub[i * KMAX + j] = (i == j) ? 100 * (1 - e) : 100 * e;
-        recount(s);
-        s.dirty = 0xFFu;
+        s.model = model_new();
+        Model& m = models[(size_t)s.model];
+        for (int i = 0; i < KK; i++) m.sub[i] = 0;
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) m.sub[i * KMAX + j] = (i == j) ? 100 * (1 - e) : 100 * e;
+        recount(m);
+        m.dirty = 0xFFFFu;
+        for (int a = 0; a < KMAX; a++) m.stale[a] = 0xFFFFu;
         s.abundance = 0; s.slot = free_slots.back(); free_slots.pop_back();
         s.tail = -1; s.node = -1; s.hash = 1469598103934665603ull; s.seqlen = 0;
         level_strains.push_back(s);
@@ -640,22 +658,29 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             sp.lab_len = sv[s].node >= 0 ? f.node_lab_len[sv[s].node] : 0;
             sp.pad = 0;
             sp.a0 = (double)sv[s].abundance;
-            sp.logpri = (double)logl(sv[s].abundance / za);
-            // log table of the strain: only the rows its counts changed in since the last level are recomputed
-            HStrain& hs = const_cast<HStrain&>(sv[s]);
-            for (int a = 0; a < KMAX; a++) {
-                if (!(hs.dirty & (1u << a))) continue;
-                const ld lc = (a < K) ? logl(a < 6 ? hs.comp[a] : (ld)0) : (ld)0;          // log comp_count[a], Strain.cpp:132-135
-                for (int b = 0; b < KMAX; b++) hs.lpc[a * KMAX + b] = (a < K && b < K) ? (double)(logl(hs.sub[a * KMAX + b]) - lc) : 0.0;
+            sp.logpri = (mode == MODE_HARD) ? (double)logl(sv[s].abundance / za) : 0.0;      // the sampler takes a0 itself
+            if (!do_update) continue;
+            // log table of the strain: only the rows its counts changed in since the last level are redone, and in
+            // them only the logarithms of the counts that changed
+            Model& hm = models[(size_t)sv[s].model];
+            for (int a = 0; a < K; a++) {
+                if (!(hm.dirty & (1u << a))) continue;
+                const ld lc = logl(a < 6 ? hm.comp[a] : (ld)0);                             // log comp_count[a], Strain.cpp:132-135
+                for (int b = 0; b < K; b++) {
+                    if (hm.stale[a] & (1u << b)) hm.lsub[a * KMAX + b] = logl(hm.sub[a * KMAX + b]);
+                    hm.lpc[a * KMAX + b] = (double)(hm.lsub[a * KMAX + b] - lc);
+                }
+                hm.stale[a] = 0;
             }
-            hs.dirty = 0;
-            if (do_update) std::memcpy(P.lpt + (size_t)s * KK, hs.lpc, sizeof(double) * KK);
+            hm.dirty = 0;
+            double* dst = P.lpt + (size_t)s * K * K;                                          // compact [K][K]
+            for (int a = 0; a < K; a++) std::memcpy(dst + a * K, hm.lpc + a * KMAX, sizeof(double) * (size_t)K);
         }
         const bool chain = (mode == MODE_SAMPLE) && S > 1 && n_sweeps > 0;
         const bool timed = chain && pa.want_timing;
         if (level_wants_grid(jd, H)) {
             // a very large level: row copies / the single-symbol update on a grid, from a device copy of the parameters
-            const size_t bytes = offsetof(LevelParams, lpt) + sizeof(double) * (size_t)S * KK;
+            const size_t bytes = offsetof(LevelParams, lpt) + sizeof(double) * (size_t)S * K * K;
             HIPCHK(hipMemcpyAsync(Pd, Ph, bytes, hipMemcpyHostToDevice, st));
             H.done = launch_level_grid(st, jd, H, Pd);
             HIPCHK(hipStreamSynchronize(st));            // the level's kernel runs on another stream
@@ -727,7 +752,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 std::vector<HStrain> kept;
                 std::vector<char> keep(level_strains.size(), 0);
                 for (int j : merged) { kept.push_back(level_strains[j]); keep[j] = 1; }
-                for (size_t i = 0; i < level_strains.size(); i++) if (!keep[i]) free_slots.push_back(level_strains[i].slot);
+                for (size_t i = 0; i < level_strains.size(); i++) if (!keep[i]) drop(level_strains[i], free_slots);
                 level_strains.swap(kept);
                 final_strains = level_strains;
             }
@@ -737,6 +762,9 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         if (Rn > 0 && !level_strains.empty()) {
             const int S = (int)level_strains.size();
             if (S > MAXS) throw ScError(SC_ERR_CAPACITY, "more than 128 candidate strains at one level");
+            if ((long)S * K * K > (long)level_table_capacity())
+                throw ScError(SC_ERR_UNSUPPORTED, std::to_string(S) + " candidate strains over " + std::to_string(K) +
+                              " distinct symbols: their log tables do not fit the level kernel's LDS");
             bool has_dups = false, any_multi = false;
             for (int x = e0; x < e1; x++) { if (!f.ent_first[x]) has_dups = true; if (f.ent_lab_len[x] != 1) any_multi = true; }
             for (auto& s : level_strains) if (f.node_lab_len[s.node] != 1) any_multi = true;
@@ -744,16 +772,17 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             if (branching) {
                 // np_bayes_clustering, :128-244 (+ pruning :404-454)
                 const int n = std::min(pa.sweeps_cap, pa.draw_budget / Q);
-                std::vector<uint64_t> hs(S); std::vector<int> ln(S), last(S);
-                for (int s = 0; s < S; s++) { hs[s] = level_strains[s].hash; ln[s] = level_strains[s].seqlen; }
+                int last[MAXS];
                 for (int s = 0; s < S; s++) {
                     last[s] = s;
-                    for (int t = S - 1; t > s; t--) if (hs[t] == hs[s] && ln[t] == ln[s]) { last[s] = t; break; }
+                    for (int t = S - 1; t > s; t--)
+                        if (level_strains[t].hash == level_strains[s].hash && level_strains[t].seqlen == level_strains[s].seqlen) { last[s] = t; break; }
                 }
-                std::vector<ld> prior(S), post(S), a(S);
+                ld prior[MAXS], post[MAXS], a[MAXS];
                 for (int s = 0; s < S; s++) prior[s] = level_strains[last[s]].abundance;
                 run_level(MODE_SAMPLE, e0, e1, Q, n, true, level_strains, has_dups, any_multi);
-                std::vector<std::vector<ld>> cnt(S, std::vector<ld>(KMAX, 0));
+                static thread_local ld cnt[MAXS][KMAX];
+                for (int s = 0; s < S; s++) for (int b = 0; b < KMAX; b++) cnt[s][b] = 0;
                 if (S == 1 || n <= 0) {
                     // a single weight consumes no random numbers (libstdc++ discrete_distribution)
                     a[0] = level_strains[0].abundance;
@@ -777,15 +806,17 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 for (int s = 0; s < S; s++) a[s] *= Q;
                 for (int s = 0; s < S; s++) {
                     HStrain& st_ = level_strains[s];
+                    Model& m_ = models[(size_t)st_.model];
                     st_.abundance += a[s];                                   // update_model, Strain.cpp:106-125
                     if (f.node_lab_len[st_.node] == 1) {
                         const int la = f.labels[f.node_lab_off[st_.node]];
                         if (la < KMAX) {
-                            for (int b = 0; b < K; b++) if (cnt[s][b] > 0) st_.sub[la * KMAX + b] += cnt[s][b] / n;
-                            st_.dirty |= 1u << la;
+                            for (int b = 0; b < K; b++)
+                                if (cnt[s][b] > 0) { m_.sub[la * KMAX + b] += cnt[s][b] / n; m_.stale[la] |= (uint16_t)(1u << b); }
+                            m_.dirty |= 1u << la;
                         }
                     }
-                    recount(st_);
+                    recount(m_);
                 }
                 for (int s = 0; s < S; s++) post[s] = level_strains[last[s]].abundance;
                 ld A_delta_max = 0;
@@ -796,7 +827,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 std::vector<HStrain> kept;
                 for (int s = 0; s < S; s++) {
                     const ld d = post[s] - prior[s];
-                    if (a[s] < Zt || d < 0.01 * A_delta_max) free_slots.push_back(level_strains[s].slot);
+                    if (a[s] < Zt || d < 0.01 * A_delta_max) drop(level_strains[s], free_slots);
                     else kept.push_back(level_strains[s]);
                 }
                 level_strains.swap(kept);
@@ -805,14 +836,16 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 run_level(MODE_HARD, e0, e1, Q, 0, true, level_strains, has_dups, any_multi);
                 for (int s = 0; s < S; s++) {
                     HStrain& st_ = level_strains[s];
+                    Model& m_ = models[(size_t)st_.model];
                     st_.abundance += (ld)Rh->abund[s];
+                    const double* sub_d = Rh->subst + (size_t)s * K * K;      // compact [K][K]
                     for (int a = 0; a < K; a++)
                         for (int b = 0; b < K; b++) {
-                            const double d = Rh->subst[s * KK + a * KMAX + b];
-                            st_.sub[a * KMAX + b] += (ld)d;
-                            if (d != 0.0) st_.dirty |= 1u << a;
+                            const double d = sub_d[a * K + b];
+                            m_.sub[a * KMAX + b] += (ld)d;
+                            if (d != 0.0) { m_.dirty |= 1u << a; m_.stale[a] |= (uint16_t)(1u << b); }
                         }
-                    recount(st_);
+                    recount(m_);
                 }
             }
         }
@@ -857,16 +890,18 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         // materialise: the first surviving child of a parent inherits its row, the others copy it
         std::vector<int> first_child(level_strains.size(), -1);
         for (int c = 0; c < (int)cands.size(); c++) if (first_child[cands[c].parent] < 0) first_child[cands[c].parent] = c;
-        for (size_t p = 0; p < level_strains.size(); p++) if (first_child[p] < 0) free_slots.push_back(level_strains[p].slot);
+        for (size_t p = 0; p < level_strains.size(); p++) if (first_child[p] < 0) drop(level_strains[p], free_slots);
         sub_strains.clear();
         for (int c = 0; c < (int)cands.size(); c++) {
             const HStrain& par = level_strains[cands[c].parent];
             HStrain ns = par;
-            if (first_child[cands[c].parent] == c) ns.slot = par.slot;
+            if (first_child[cands[c].parent] == c) { ns.slot = par.slot; ns.model = par.model; }
             else {
                 if (free_slots.empty()) throw ScError(SC_ERR_CAPACITY, "out of read_loglik rows");
                 ns.slot = free_slots.back(); free_slots.pop_back();
                 pending_copies.push_back({par.slot, ns.slot});
+                ns.model = model_new();                                  // (may move the pool: take the source by index)
+                models[(size_t)ns.model] = models[(size_t)par.model];
             }
             arena.push_back({cands[c].node, par.tail});
             ns.tail = (int)arena.size() - 1; ns.node = cands[c].node;

@@ -7,8 +7,8 @@
 namespace sc {
 
 constexpr int MAXS = 128;        // candidate strains alive at one level (reference keeps <= ~81)
-constexpr int KMAX = 8;          // symbols: A C G T - = plus up to two others (e.g. N)
-constexpr int KK = KMAX * KMAX;
+constexpr int KMAX = 16;         // symbols: A C G T - = plus up to ten others (N and the IUPAC codes of a 16S reference)
+constexpr int KK = KMAX * KMAX;  // capacity; the tables of a level are compact [K][K] with K = symbols of the window
 constexpr int MAX_DRAWS = 40000; // NonparametricClustering.cpp:160 / :781 draw budget
 
 enum LevelMode { MODE_HARD = 0, MODE_SAMPLE = 1 };
@@ -72,7 +72,7 @@ struct StrainParam {
 struct LevelParams {
     int copy_src[MAXS], copy_dst[MAXS];
     StrainParam sp[MAXS];
-    double lpt[MAXS * KK];       // log sub(a,b) - log comp(a) per strain
+    double lpt[MAXS * KK];       // log sub(a,b) - log comp(a): compact [S][K][K], K = JobDev::K
 };
 
 // One launch serves the current level of up to MAXB regions: workgroup b takes batch.it[b].  Everything the
@@ -93,7 +93,7 @@ struct LevelBatch { LevelItem it[MAXB]; };
 // Per-level results, written by the kernel into host-mapped pinned memory; `seq` last (system-scope release).
 struct LevelResult {
     double abund[MAXS];          // HARD: sum of responsibilities; SAMPLE: urn weights a[] after the sweeps
-    double subst[MAXS * KK];     // HARD: responsibility-weighted substitution counts
+    double subst[MAXS * KK];     // HARD: responsibility-weighted substitution counts, compact [S][K][K]
     unsigned cnt[MAXS * KMAX];   // SAMPLE: draws per (strain, read symbol)
     unsigned kdraw[MAXS];        // SAMPLE: draws per strain (abund = a0 + kdraw, exactly)
     unsigned long long n_draws;

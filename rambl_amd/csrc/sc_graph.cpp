@@ -561,7 +561,7 @@ void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>&
     ThreadTables T;
     thread(G, R, cig, T);
     const int INF = 0x7fffffff;
-    if ((int)T.sym.size() > 8) throw std::runtime_error("more than 8 distinct read/reference symbols");
+    if ((int)T.sym.size() > 8) throw std::runtime_error("more than 8 distinct symbols in the reads");
 
     enum { EV_SIB = 0, EV_CHAIN = 1, EV_EDGE = 2 };
     enum { REF_CLASS = 0, REF_NODE = 1, REF_CHAIN = 2 };
@@ -692,7 +692,7 @@ void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>&
     });
     // replay
     std::vector<int> class_node((size_t)glen * 8, -1);
-    for (int i = 0; i < glen; i++) class_node[(size_t)i * 8 + ref_code(i)] = i + 1;
+    for (int i = 0; i < glen; i++) if (ref_code(i) < 8) class_node[(size_t)i * 8 + ref_code(i)] = i + 1;   // a gene base no read carries has no class
     auto resolve = [&](const NodeRef& x) -> int {
         if (x.type == REF_NODE) return x.a;
         if (x.type == REF_CLASS) return class_node[(size_t)x.a * 8 + x.b];
@@ -880,7 +880,7 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
         sub.clear();
     }
     f.n_levels = level;
-    if (f.K > 7 && f.unsupported.empty()) f.unsupported = "more than 7 distinct symbols in node/read labels";
+    if (f.K > 16 && f.unsupported.empty()) f.unsupported = "more than 16 distinct symbols in node/read labels";
 }
 
 }  // namespace sc

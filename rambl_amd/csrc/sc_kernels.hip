@@ -29,10 +29,10 @@ namespace sc {
 #define SC_LDS __attribute__((address_space(3)))
 
 constexpr int LDS_TOTAL = 160 * 1024 - 256;   // dynamic part; the rest covers small static __shared__ variables
-constexpr int LDS_SMALL = 13 * 1024;           // per-strain scalars (LevelLds)
+constexpr int LDS_SMALL = 17 * 1024;           // per-strain scalars (LevelLds)
 constexpr int LDS_BIG = LDS_TOTAL - LDS_SMALL;
 static_assert(LDS_SMALL >= (int)(sizeof(double) * 2 * MAXS + sizeof(StrainParam) * MAXS + sizeof(unsigned) * MAXS * KMAX + sizeof(int) * 5 * MAXS + 64), "LDS_SMALL");
-static_assert(LDS_BIG >= (int)(sizeof(double) * MAXS * KK), "LDS_BIG");
+static_assert(LDS_BIG >= (int)(sizeof(double) * MAXS * 64), "LDS_BIG");    // every level with <= 8 symbols stages its log tables in LDS
 
 // --------------------------------------------------------------------------
 // wave64 helpers
@@ -486,9 +486,9 @@ __global__ __launch_bounds__(256) void k_level_update(JobDev job, LevelHdr h, co
     __syncthreads();
     for (int i = tid; i < S * KMAX; i += blockDim.x) {
         const int sx = i / KMAX, b = i % KMAX, a = s_lab[sx];
-        const double* lp = P->lpt + (long)sx * KK;
-        s_row[i] = (a < KMAX) ? lp[a * KMAX + b] : 0.0;
-        s_diag[i] = lp[b * KMAX + b];
+        const double* lp = P->lpt + (long)sx * K * K;                  // compact [K][K] table of the strain
+        s_row[i] = (a < K && b < K) ? lp[a * K + b] : 0.0;
+        s_diag[i] = (b < K) ? lp[b * K + b] : 0.0;
     }
     __syncthreads();
     const long total = (long)S * Rn;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void k_level_update(JobDev job, LevelHdr h, co
 // The per-strain parameters of the level, straight from host-mapped memory into LDS: 16-byte loads over PCIe,
 // every thread a few, one round trip.
 __device__ __forceinline__ void stage_params(const LevelHdr& h, const LevelParams* __restrict__ P, StrainParam* s_sp, int* s_copy,
-                                             double* s_lpt, bool want_lpt, int tid, int nt) {
+                                             double* s_lpt, bool want_lpt, int K2, int tid, int nt) {
     const i4v* src_sp = reinterpret_cast<const i4v*>(P->sp);
     i4v* dst_sp = reinterpret_cast<i4v*>(s_sp);
     for (int i = tid; i < h.S * 2; i += nt) dst_sp[i] = src_sp[i];
@@ -519,7 +519,7 @@ __device__ __forceinline__ void stage_params(const LevelHdr& h, const LevelParam
     if (want_lpt) {
         const double2* s = reinterpret_cast<const double2*>(P->lpt);
         double2* d = reinterpret_cast<double2*>(s_lpt);
-        for (int i = tid; i < h.S * (KK / 2); i += nt) d[i] = s[i];
+        for (int i = tid; i < (h.S * K2 + 1) / 2; i += nt) d[i] = s[i];
     }
 }
 
@@ -544,7 +544,7 @@ __device__ __forceinline__ void phase_copies(const JobDev& job, const LevelHdr& 
 // present in read_loglik (`has`).  s_lpt: the strains' log tables in LDS.
 __device__ __forceinline__ void phase_update(const JobDev& job, const LevelHdr& h, const StrainParam* s_sp, const double* s_lpt,
                                              int tid, int nt) {
-    const int S = h.S, K = job.K, e0 = h.e0, Rn = h.e1 - h.e0;
+    const int S = h.S, K = job.K, K2 = K * K, e0 = h.e0, Rn = h.e1 - h.e0;
     const long stride = job.ll_stride;
     for (int r = tid; r < Rn; r += nt) {
         const int e = e0 + r;
@@ -558,13 +558,13 @@ __device__ __forceinline__ void phase_update(const JobDev& job, const LevelHdr& 
         const uint8_t* sb = job.labels + s_sp[s].lab_off;
         const uint8_t* rb = job.labels + job.ent_lab_off[e];
         const int ls = s_sp[s].lab_len, lr = job.ent_lab_len[e];
-        const double* lp = s_lpt + s * KK;
+        const double* lp = s_lpt + s * K2;
         double val;
         if (ls == 1) {
             int a = sb[0], b = rb[0];
             if (lr == 1) {
                 if (a == codeN) a = b;
-                val = (a < K && b < K) ? lp[a * KMAX + b] : __longlong_as_double(0x7ff8000000000000ll);
+                val = (a < K && b < K) ? lp[a * K + b] : __longlong_as_double(0x7ff8000000000000ll);
             } else {
                 // logprob(sb, "multi"): sub_count[(sb, rb)] is created as 0 (std::map operator[]), so the
                 // result is log 0 - log comp(sb) = -inf for a symbol of the alphabet; for N (sb becomes rb)
@@ -578,14 +578,14 @@ __device__ __forceinline__ void phase_update(const JobDev& job, const LevelHdr& 
                 while (ii > 0 && jj > 0) {
                     int a = sb[--ii], b = rb[--jj];
                     if (a == codeN) a = b;
-                    val += lp[a * KMAX + b];
+                    val += lp[a * K + b];
                 }
             } else {
                 int ii = 0, jj = 0;
                 while (ii < ls && jj < lr) {
                     int a = sb[ii++], b = rb[jj++];
                     if (a == codeN) a = b;
-                    val += lp[a * KMAX + b];
+                    val += lp[a * K + b];
                 }
             }
         }
@@ -627,7 +627,7 @@ __device__ __forceinline__ void phase_update(const JobDev& job, const LevelHdr& 
                 int a = job.labels[s_sp[sidx[k]].lab_off];
                 const int b = bsym[k];
                 if (a == codeN) a = b;
-                const double val = (a < K && b < K) ? s_lpt[sidx[k] * KK + a * KMAX + b] : __longlong_as_double(0x7ff8000000000000ll);
+                const double val = (a < K && b < K) ? s_lpt[sidx[k] * K2 + a * K + b] : __longlong_as_double(0x7ff8000000000000ll);
                 if (live[k]) *cell[k] = fresh[k] ? val : (old[k] + val);       // Strain::update_read_loglik, Strain.cpp:85-95
             }
         }
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(LevelBatch batch
     const int S = h.S, Q = h.Q, e0 = h.e0, Rn = h.e1 - h.e0;
     const int stride = chain_w_stride(S);
     const bool upd = h.do_update && Rn > 0;
-    stage_params(h, P, l.s_sp, l.s_copy, reinterpret_cast<double*>(l.s_big), upd && !(h.done & LV_ITEMS_DONE), tid, nt);
+    stage_params(h, P, l.s_sp, l.s_copy, reinterpret_cast<double*>(l.s_big), upd && !(h.done & LV_ITEMS_DONE), job.K * job.K, tid, nt);
     for (int i = tid; i < MAXS * KMAX; i += nt) l.s_cnt[i] = 0;
     if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_pass = 0; R->chain_cycles = 0; R->chain_wall = 0; }
     __syncthreads();
@@ -820,12 +820,12 @@ __global__ __launch_bounds__(512) void k_level(LevelBatch batch) {
     const LevelParams* __restrict__ P = it.P;
     LevelResult* __restrict__ R = it.R;
     const LevelLds l = level_lds(s_raw);
-    double* s_tab = reinterpret_cast<double*>(l.s_big);          //   [MAXS*KK] lpt, later the substitution histogram
+    double* s_tab = reinterpret_cast<double*>(l.s_big);          //   [S][K][K] log tables, later the substitution histogram
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int S = h.S, K = job.K, e0 = h.e0, Rn = h.e1 - h.e0;
+    const int S = h.S, K = job.K, K2 = K * K, e0 = h.e0, Rn = h.e1 - h.e0;
     const long stride = job.ll_stride;
     const bool upd = h.do_update && Rn > 0;
-    stage_params(h, P, l.s_sp, l.s_copy, s_tab, upd && !(h.done & LV_ITEMS_DONE), tid, nt);
+    stage_params(h, P, l.s_sp, l.s_copy, s_tab, upd && !(h.done & LV_ITEMS_DONE), K2, tid, nt);
     if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_pass = 0; R->chain_cycles = 0; R->chain_wall = 0; }
     __syncthreads();
     if (tid == 0) R->phase_ticks[0] = (unsigned)(wall_clock64() - wall0);
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(512) void k_level(LevelBatch batch) {
             *cell = exp(*cell - m) / norm;
         }
     }
-    for (int i = tid; i < S * KK; i += nt) s_tab[i] = 0.0;
+    for (int i = tid; i < S * K2; i += nt) s_tab[i] = 0.0;
     __syncthreads();
     if (tid == 0) R->phase_ticks[4] = (unsigned)(wall_clock64() - wall0);
     if (!h.any_multi) {
@@ -891,14 +891,14 @@ __global__ __launch_bounds__(512) void k_level(LevelBatch batch) {
 #pragma unroll 8
                 for (int q = 0; q < Q; q++) acc += (job.qcode[q] == b) ? prow[q] : 0.0;
                 const int a = job.labels[l.s_sp[s].lab_off];
-                s_tab[s * KK + a * KMAX + b] = acc;
+                s_tab[s * K2 + a * K + b] = acc;
             }
         }
     } else {
         if (tid < S) {
             const int s = tid;
             const double* prow = job.tabA + (long)s * job.qcap;
-            double* hist = s_tab + s * KK;
+            double* hist = s_tab + s * K2;
             const uint8_t* sb = job.labels + l.s_sp[s].lab_off;
             const int ls = l.s_sp[s].lab_len;
             double acc = 0;
@@ -909,20 +909,20 @@ __global__ __launch_bounds__(512) void k_level(LevelBatch batch) {
                 const uint8_t* rb = job.labels + job.ent_lab_off[e];
                 const int lr = job.ent_lab_len[e];
                 if (lr == 1) {
-                    if (ls == 1) hist[sb[0] * KMAX + rb[0]] += p;
+                    if (ls == 1) hist[sb[0] * K + rb[0]] += p;
                 } else if (job.isnew[r]) {
                     int i = ls, j = lr;
-                    while (i > 0 && j > 0) { int a = sb[--i], b = rb[--j]; hist[a * KMAX + b] += p; }
+                    while (i > 0 && j > 0) { int a = sb[--i], b = rb[--j]; hist[a * K + b] += p; }
                 } else {
                     int i = 0, j = 0;
-                    while (i < ls && j < lr) { int a = sb[i++], b = rb[j++]; hist[a * KMAX + b] += p; }
+                    while (i < ls && j < lr) { int a = sb[i++], b = rb[j++]; hist[a * K + b] += p; }
                 }
             }
             R->abund[s] = acc;
         }
     }
     __syncthreads();
-    for (int i = tid; i < S * KK; i += nt) R->subst[i] = s_tab[i];
+    for (int i = tid; i < S * K2; i += nt) R->subst[i] = s_tab[i];
     finish_level(h, R, wall0, tid);
 }
 // --------------------------------------------------------------------------
@@ -1236,7 +1236,7 @@ void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node
     hipLaunchKernelGGL(k_edge_support, dim3(blocks), dim3(256), 0, st, out_ptr, out_node, pool_ptr, pool_rid, pool_cn,
                        node_is_end, edge_src, n_edges, sorted, support);
 }
-constexpr size_t LEVEL_LDS = LDS_SMALL + sizeof(double) * MAXS * KK;
+constexpr size_t LEVEL_LDS = LDS_TOTAL;        // the log tables / histogram of S strains over K symbols: S * K * K doubles
 constexpr size_t CHAIN_LDS = LDS_TOTAL;
 template <int NB, bool L> static int set_sample_attr() {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level_sample<NB, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
@@ -1254,6 +1254,8 @@ int init_kernels() {
     rc |= set_sample_attr<8, true>(); rc |= set_sample_attr<8, false>();
     return rc;
 }
+// doubles of LDS a level can spend on the strains' log tables / the soft update's histogram: S * K * K must fit
+int level_table_capacity() { return LDS_BIG / (int)sizeof(double); }
 // A level of ordinary size is ONE launch (launch_level_batch).  Only when a level has so many (strain, read) items or
 // such long rows that a single workgroup would crawl (unthinned deep coverage) do the row copies and the
 // single-symbol update run on a grid first; `Pd` is then a device copy of the parameters the caller has put

@@ -36,8 +36,7 @@ int main(int argc, char** argv) {
     sc::ThreadFn thr = [](const std::string& G, const std::vector<sc::AlignedRead>& R,
                           const std::vector<std::vector<sc::CigarOp>>& cig, sc::ThreadTables& T) {
         const int glen = (int)G.size(), n = (int)R.size(), ncls = glen * 8, INF = 0x7fffffff;
-        bool present[256] = {false};
-        for (unsigned char c : G) present[c] = true;
+        bool present[256] = {false};                          // read symbols only, as the device stage codes them
         for (auto& r : R) for (unsigned char c : r.seq) present[c] = true;
         for (int c = 0; c < 256; c++) T.lut[c] = 0xFF;
         for (char c : {'A', 'C', 'G', 'T'}) { T.lut[(unsigned char)c] = (uint8_t)T.sym.size(); T.sym.push_back(c); }

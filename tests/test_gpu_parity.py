@@ -179,22 +179,49 @@ def test_unthinned_deep_coverage_no_sweeps(tmp_path, oracle_bin):
     T.compare_traces(open(tf).read(), exp_tr)
 
 
-def test_more_than_seven_symbols_is_reported_not_guessed(tmp_path):
-    """Labels with more than 7 distinct symbols are outside the device model: SC_ERR_UNSUPPORTED."""
-    from rambl_amd import capi, synth
+def _with_codes_in_gene(args, codes, n, seed):
+    """Overwrite n positions of the gene FASTA of a generated case with the given symbols."""
+    fa = args[-2]
+    lines = open(fa).read().split("\n")
+    idx = [i for i, l in enumerate(lines) if l and not l.startswith(">")]
+    seq = list("".join(lines[i] for i in idx))
+    rng = random.Random(seed)
+    for k in range(n):
+        seq[rng.randrange(len(seq))] = codes[k % len(codes)]
+    seq = "".join(seq)
+    k = 0
+    for i in idx:
+        m = len(lines[i])
+        lines[i] = seq[k:k + m]
+        k += m
+    open(fa, "w").write("\n".join(lines))
+
+
+@pytest.mark.parametrize("seed", [2, 5, 9, 14])
+def test_iupac_codes_in_the_gene(seed, tmp_path, oracle_bin):
+    """GreenGenes references carry R Y K M S W N: symbols outside {A,C,G,T,-,=}.  The reference's Strain tables are
+    std::map-keyed and take any byte (Strain.cpp:127-150: a never-set count is created as 0 -> log 0); the device
+    tables are [K][K] over the symbols of the window, up to 16.  A gene with seven different codes (13 symbols in
+    the labels); the oracle was checked against the reference itself on exactly these inputs (FASTA and 17-digit
+    trace byte for byte).  Reads that carry such codes themselves crash the reference (segmentation fault): no parity
+    to speak of, not tested."""
     d = str(tmp_path)
-    gene = synth.make_gene(5, glen=300, n_strains=1, n_reads=60, rlen=120, err=0.0, n_sub=0, n_ins=0, n_del=0, name="odd")
-    lines = []
-    for k, ln in enumerate(gene["sam_lines"]):
-        f = ln.split("\t")
-        if k % 7 == 0:
-            s = list(f[9])
-            s[10] = "RY"[k % 2]       # IUPAC codes: two extra symbols on top of A C G T - =
-            f[9] = "".join(s)
-        lines.append("\t".join(f))
-    gene["sam_lines"] = lines
-    fa, sam = synth.write_dataset(d, [gene])
-    args = ["-r", "odd:1-300"] + T.RAMBL_ARGS + [fa, sam]
+    args = T.make_case(seed, d)
+    _with_codes_in_gene(args, "RYKMSWN", 14, seed)
+    exp_fa, exp_tr = T.run_oracle(args, d, trace=True)
+    exp_g, _ = T.run_oracle(args, d, graph=True)
+    tf = os.path.join(d, "trace.txt")
+    assert T.run_product(args, graph=True) == exp_g
+    assert T.run_product(args, trace_file=tf) == exp_fa
+    T.compare_traces(open(tf).read(), exp_tr)
+
+
+def test_more_than_sixteen_symbols_is_reported_not_guessed(tmp_path):
+    """Labels with more than 16 distinct symbols are outside the device model: SC_ERR_UNSUPPORTED."""
+    from rambl_amd import capi
+    d = str(tmp_path)
+    args = T.make_case(3, d)
+    _with_codes_in_gene(args, "RYKMSWBDHVN", 22, 3)       # 6 + 11 symbols
     with pytest.raises(capi.StrainCallError) as e:
         T.run_product(args)
     assert e.value.code == -4
