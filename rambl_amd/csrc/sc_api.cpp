@@ -482,6 +482,29 @@ static void recount(Model& s) {                                           // Str
         s.Z += s.comp[i];
     }
 }
+}  // namespace sc
+// The reference adds 1 to a candidate's weight once per draw, in x87 long double (NonparametricClustering.cpp:195): k
+// separate roundings, not one.  Inside a binade every a + j is exact (1 is a multiple of the unit in the last place
+// while a < 2^64), so the only additions that round are the ones that cross into the next binade: the same k additions
+// in O(log k) steps, bit for bit (tests/native/add_ones_check.cpp compares it with the literal loop).
+extern "C" long double sc_add_ones(long double a, unsigned long k) {
+    if (!std::isfinite((double)a) && !(a == a && a - a == 0)) return a + (long double)k;       // inf / NaN stay what they are
+    while (k > 0) {
+        if (!(a >= 1)) { a += 1; k--; continue; }            // below 1 (or negative): the literal addition, at most a few times
+        int e;
+        (void)frexpl(a, &e);                                 // a in [2^(e-1), 2^e)
+        const long double top = ldexpl(1.0L, e);
+        const long double room = top - a;                    // exact (Sterbenz)
+        if (!(room >= 1) && !(room > 0)) { a += 1; k--; continue; }
+        const long double jr = ceill(room) - 1;              // additions that stay below the next power of two
+        if (jr >= (long double)k) return a + (long double)k;
+        const unsigned long j = (unsigned long)jr;
+        a += (long double)j; k -= j;                         // exact
+        a += 1; k--;                                         // the crossing one rounds like the reference's
+    }
+    return a;
+}
+namespace sc {
 static uint64_t hash_extend(uint64_t h, const std::string& lab) {
     for (unsigned char c : lab) { h ^= c; h *= 1099511628211ull; }
     return h;
@@ -789,14 +812,13 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                     for (int s = 1; s < S; s++) a[s] = level_strains[s].abundance;
                     if (n > 0) {
                         const long tot = (long)n * Q;
-                        for (long t = 0; t < tot; t++) a[0] += 1;
+                        a[0] = sc_add_ones(a[0], (unsigned long)tot);
                         for (int x = e0; x < e1; x++)
                             if (f.ent_lab_len[x] == 1) cnt[0][f.labels[f.ent_lab_off[x]]] += (ld)n * f.ent_cn[x];
                     }
                 } else {
                     for (int s = 0; s < S; s++) {
-                        a[s] = level_strains[s].abundance;
-                        for (unsigned t = 0; t < Rh->kdraw[s]; t++) a[s] += 1;     // a[c] += 1 per draw, :195 (one rounding per draw)
+                        a[s] = sc_add_ones(level_strains[s].abundance, Rh->kdraw[s]);     // a[c] += 1 per draw, :195 (one rounding per draw)
                         for (int b = 0; b < KMAX; b++) cnt[s][b] = (ld)Rh->cnt[s * KMAX + b];
                     }
                 }
@@ -923,13 +945,12 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         std::vector<ld> a(S);
         if (S == 1 || n <= 0) {
             for (int s = 0; s < S; s++) a[s] = fs[s].abundance;
-            if (n > 0) { const long tot = (long)n * Q; for (long t = 0; t < tot; t++) a[0] += 1; }
+            if (n > 0) a[0] = sc_add_ones(a[0], (unsigned long)((long)n * Q));
         } else {
             pending_copies.clear();
             run_level(MODE_SAMPLE, final_e0, final_e0 + n_reads, Q, n, false, fs, false, true);
             for (int s = 0; s < S; s++) {
-                a[s] = fs[s].abundance;
-                for (unsigned t = 0; t < Rh->kdraw[s]; t++) a[s] += 1;             // :823, one rounding per draw
+                a[s] = sc_add_ones(fs[s].abundance, Rh->kdraw[s]);                   // :823, one rounding per draw
             }
         }
         ld z = 0;

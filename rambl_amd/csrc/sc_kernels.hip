@@ -29,9 +29,9 @@ namespace sc {
 #define SC_LDS __attribute__((address_space(3)))
 
 constexpr int LDS_TOTAL = 160 * 1024 - 256;   // dynamic part; the rest covers small static __shared__ variables
-constexpr int LDS_SMALL = 17 * 1024;           // per-strain scalars (LevelLds)
+constexpr int LDS_SMALL = 18 * 1024;           // per-strain scalars (LevelLds)
 constexpr int LDS_BIG = LDS_TOTAL - LDS_SMALL;
-static_assert(LDS_SMALL >= (int)(sizeof(double) * 2 * MAXS + sizeof(StrainParam) * MAXS + sizeof(unsigned) * MAXS * KMAX + sizeof(int) * 5 * MAXS + 64), "LDS_SMALL");
+static_assert(LDS_SMALL >= (int)(sizeof(double) * 2 * MAXS + sizeof(StrainParam) * MAXS + sizeof(unsigned) * MAXS * KMAX + sizeof(int) * 6 * MAXS + 64), "LDS_SMALL");
 static_assert(LDS_BIG >= (int)(sizeof(double) * MAXS * 64), "LDS_BIG");    // every level with <= 8 symbols stages its log tables in LDS
 
 // --------------------------------------------------------------------------
@@ -536,14 +536,15 @@ __device__ __forceinline__ void phase_copies(const JobDev& job, const LevelHdr& 
             dst[i] = v0; dst[i + nt] = v1; dst[i + 2 * nt] = v2; dst[i + 3 * nt] = v3;
         }
         for (; i < n2; i += nt) dst[i] = src[i];
-        __syncthreads();                       // a later copy may read this row
     }
+    // the copies are independent (a destination is a free row, a source a surviving parent's row): one barrier for all
+    __syncthreads();
 }
 
 // phase 1: read log-likelihood update, NonparametricClustering.cpp:343-391, then the reads of the level are
 // present in read_loglik (`has`).  s_lpt: the strains' log tables in LDS.
-__device__ __forceinline__ void phase_update(const JobDev& job, const LevelHdr& h, const StrainParam* s_sp, const double* s_lpt,
-                                             int tid, int nt) {
+__device__ __forceinline__ void phase_update(const JobDev& job, const LevelHdr& h, const StrainParam* s_sp, const int* s_lab,
+                                             const double* s_lpt, int tid, int nt) {
     const int S = h.S, K = job.K, K2 = K * K, e0 = h.e0, Rn = h.e1 - h.e0;
     const long stride = job.ll_stride;
     for (int r = tid; r < Rn; r += nt) {
@@ -596,39 +597,34 @@ __device__ __forceinline__ void phase_update(const JobDev& job, const LevelHdr& 
     if (h.done & LV_ITEMS_DONE) {
         // k_level_update has applied the items
     } else if (!h.has_dups && !h.any_multi) {
-        // single-symbol labels everywhere (the usual level): four items per thread in flight,
-        // so the dependent loads entry -> read id -> log-likelihood cell overlap
-        const long total = (long)S * Rn;
-        constexpr int U = 4;
-        for (long base = tid; base < total; base += (long)U * nt) {
-            int sidx[U], rid[U], bsym[U];
-            bool live[U], fresh[U];
-            double* cell[U];
-            double old[U];
+        // single-symbol labels everywhere (the usual level): a thread takes a read of the level and walks the strains
+        // eight at a time, so eight independent row cells are in flight per thread and neighbouring threads (reads
+        // sorted by position: neighbouring ids) touch neighbouring cells of each row
+        constexpr int U = 8;
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+        for (int r = tid; r < Rn; r += nt) {
+            const int e = e0 + r;
+            const int rid = job.ent_rid[e];
+            const int b = job.labels[job.ent_lab_off[e]];
+            const bool fresh = job.isnew[r] != 0;
+            for (int s0 = 0; s0 < S; s0 += U) {
+                double* cell[U];
+                double old[U];
 #pragma unroll
-            for (int k = 0; k < U; k++) {
-                const long idx = base + (long)k * nt;
-                live[k] = idx < total;
-                const long ii = live[k] ? idx : 0;
-                sidx[k] = (int)(ii / Rn);
-                const int e = e0 + (int)(ii % Rn);
-                rid[k] = job.ent_rid[e];
-                bsym[k] = job.labels[job.ent_lab_off[e]];
-                fresh[k] = job.ent_first[e] != 0;
-            }
+                for (int k = 0; k < U; k++) {
+                    const int sx = (s0 + k < S) ? s0 + k : S - 1;
+                    cell[k] = job.ll + (long)s_sp[sx].slot * stride + rid;
+                    old[k] = fresh ? 0.0 : *cell[k];
+                }
 #pragma unroll
-            for (int k = 0; k < U; k++) {
-                cell[k] = job.ll + (long)s_sp[sidx[k]].slot * stride + rid[k];
-                fresh[k] = fresh[k] && !job.has[rid[k]];
-                old[k] = *cell[k];
-            }
-#pragma unroll
-            for (int k = 0; k < U; k++) {
-                int a = job.labels[s_sp[sidx[k]].lab_off];
-                const int b = bsym[k];
-                if (a == codeN) a = b;
-                const double val = (a < K && b < K) ? s_lpt[sidx[k] * K2 + a * K + b] : __longlong_as_double(0x7ff8000000000000ll);
-                if (live[k]) *cell[k] = fresh[k] ? val : (old[k] + val);       // Strain::update_read_loglik, Strain.cpp:85-95
+                for (int k = 0; k < U; k++) {
+                    const int sx = s0 + k;
+                    if (sx >= S) break;
+                    int a = s_lab[sx];
+                    if (a == codeN) a = b;
+                    const double val = (a < K && b < K) ? s_lpt[sx * K2 + a * K + b] : qnan;
+                    *cell[k] = fresh ? val : (old[k] + val);       // Strain::update_read_loglik, Strain.cpp:85-95
+                }
             }
         }
     } else if (!h.has_dups) {
@@ -682,7 +678,7 @@ __host__ __device__ inline int chain_w_stride(int S) {
 // LDS of the level kernels: per-strain scalars first, then one big region that holds the strains' log tables
 // during the update and the sampler's uniforms + weight rows (or the soft update's histogram) afterwards.
 struct LevelLds {
-    double* s_a; double* s_p; unsigned* s_cnt; int* s_slot; unsigned* s_kf; float* s_a0f; int* s_x; int* s_copy;
+    double* s_a; double* s_p; unsigned* s_cnt; int* s_slot; unsigned* s_kf; float* s_a0f; int* s_x; int* s_copy; int* s_lab;
     StrainParam* s_sp; unsigned char* s_big;
 };
 __device__ __forceinline__ LevelLds level_lds(unsigned char* raw) {
@@ -695,7 +691,8 @@ __device__ __forceinline__ LevelLds level_lds(unsigned char* raw) {
     l.s_kf = reinterpret_cast<unsigned*>(l.s_slot + MAXS);         // [MAXS] draws per strain so far
     l.s_a0f = reinterpret_cast<float*>(l.s_kf + MAXS);             // [MAXS] fp32 copy of the starting weights
     l.s_copy = reinterpret_cast<int*>(l.s_a0f + MAXS);             // [2*MAXS]
-    l.s_x = l.s_copy + 2 * MAXS;                                   // [8] first failing position per wave
+    l.s_lab = l.s_copy + 2 * MAXS;                                 // [MAXS] first symbol of the strain's node label
+    l.s_x = l.s_lab + MAXS;                                        // [8] first failing position per wave
     l.s_big = raw + LDS_SMALL;
     return l;
 }
@@ -741,10 +738,11 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(LevelBatch batch
         l.s_slot[tid] = tid < S ? l.s_sp[tid].slot : 0;
         l.s_kf[tid] = 0u;
         l.s_a0f[tid] = tid < S ? (float)l.s_sp[tid].a0 : 0.0f;
+        l.s_lab[tid] = tid < S ? (int)job.labels[l.s_sp[tid].lab_off] : 0;
     }
     phase_copies(job, h, l.s_copy, tid, nt);
     if (tid == 0) R->phase_ticks[1] = (unsigned)(wall_clock64() - wall0);
-    if (upd) phase_update(job, h, l.s_sp, reinterpret_cast<const double*>(l.s_big), tid, nt);
+    if (upd) phase_update(job, h, l.s_sp, l.s_lab, reinterpret_cast<const double*>(l.s_big), tid, nt);
     if (tid == 0) R->phase_ticks[2] = (unsigned)(wall_clock64() - wall0);
     phase_slots(job, h, tid, nt);
     if (tid == 0) R->phase_ticks[3] = (unsigned)(wall_clock64() - wall0);
@@ -760,40 +758,50 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(LevelBatch batch
         const long lstride = job.ll_stride;
         SC_GLOBAL float* rows_g = (SC_GLOBAL float*)job.tabLf;
         auto put = [&](long idx, float v) __attribute__((always_inline)) { if (ROWS_LDS) s_rows[idx] = v; else rows_g[idx] = v; };
-        for (long gid = tid; gid < (long)Q * G; gid += nt) {
-            const int g = (int)(gid % G);
-            const long q = gid / G;
-            const int s0 = g * per, s1 = (s0 + per < S) ? s0 + per : S;
-            const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
-            const bool hr = job.has[rid] != 0, hu = uid >= 0 && job.has[uid] != 0;
-            double x[8], m = -INFINITY;
+        // one (slot, lane) item per thread and step; the read / mate ids of the NEXT item (two dependent loads) are
+        // fetched while this item's row cells (eight independent loads) and weights are worked on
+        const long QG = (long)Q * G;
+        int rid_n = 0, uid_n = -1;
+        auto fetch = [&](long g_) __attribute__((always_inline)) { const long q_ = g_ / G; rid_n = job.ent_rid[e0 + job.qent[q_]]; uid_n = job.quid[q_]; };
+        if (tid < QG) fetch(tid);
+        {
+            for (long gid = tid; gid < QG; gid += nt) {          // lanes of one slot are adjacent and leave together
+                const int rid_c = rid_n, uid_c = uid_n;
+                if (gid + nt < QG) fetch(gid + nt);
+                const bool hr_c = h.do_update ? true : job.has[rid_c] != 0;      // the update has just entered the level's reads
+                const bool hu_c = uid_c >= 0 && job.has[uid_c] != 0;
+                const int g = (int)(gid % G);
+                const long q = gid / G;
+                const int s0 = g * per, s1 = (s0 + per < S) ? s0 + per : S;
+                double x[8], m = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int sx = s0 + i;
-                x[i] = -INFINITY;
-                if (sx < s1) {
-                    const double* row = job.ll + (long)l.s_slot[sx] * lstride;
-                    double v = hr ? row[rid] : 0.0;
-                    if (hu) v += row[uid];
-                    x[i] = v;
-                    m = fmax(m, v);
+                for (int i = 0; i < 8; i++) {
+                    const int sx = s0 + i;
+                    x[i] = -INFINITY;
+                    if (sx < s1) {
+                        const double* row = job.ll + (long)l.s_slot[sx] * lstride;
+                        double v = hr_c ? row[rid_c] : 0.0;
+                        if (hu_c) v += row[uid_c];
+                        x[i] = v;
+                        m = fmax(m, v);
+                    }
                 }
-            }
-            for (int d = 1; d < G; d <<= 1) m = fmax(m, __shfl_xor(m, d));       // G is a power of two <= 16: lanes of one slot are adjacent
-            const bool flag = !(m >= -600.0);                // underflow range of the reference's exp(); also NaN / -inf
-            const long Lf = q * stride;
+                for (int d = 1; d < G; d <<= 1) m = fmax(m, __shfl_xor(m, d));       // G is a power of two <= 16: lanes of one slot are adjacent
+                const bool flag = !(m >= -600.0);                // underflow range of the reference's exp(); also NaN / -inf
+                const long Lf = q * stride;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int sx = s0 + i;
-                if (sx < s1) put(Lf + sx, flag ? __int_as_float(0x7fc00000) : (float)exp(x[i] - m));
-            }
-            if (g == 0) {
-                // the read symbol rides behind the weights (a tiny denormal under a zero count: no effect on the sums)
-                const int c0 = job.qcode[q];
-                put(Lf + S, __int_as_float(c0 < KMAX ? c0 : KMAX));
-                for (int sx = S + 1; sx < stride; sx++) put(Lf + sx, 0.0f);
-                // the chain reads whole 16-strain blocks: keep what follows the last row finite
-                if (q == Q - 1) for (int i = 0; i < 16; i++) put(Lf + stride + i, 0.0f);
+                for (int i = 0; i < 8; i++) {
+                    const int sx = s0 + i;
+                    if (sx < s1) put(Lf + sx, flag ? __int_as_float(0x7fc00000) : (float)exp(x[i] - m));
+                }
+                if (g == 0) {
+                    // the read symbol rides behind the weights (a tiny denormal under a zero count: no effect on the sums)
+                    const int c0 = job.qcode[q];
+                    put(Lf + S, __int_as_float(c0 < KMAX ? c0 : KMAX));
+                    for (int sx = S + 1; sx < stride; sx++) put(Lf + sx, 0.0f);
+                    // the chain reads whole 16-strain blocks: keep what follows the last row finite
+                    if (q == Q - 1) for (int i = 0; i < 16; i++) put(Lf + stride + i, 0.0f);
+                }
             }
         }
     }
@@ -829,9 +837,10 @@ __global__ __launch_bounds__(512) void k_level(LevelBatch batch) {
     if (tid == 0) { R->error = 0; R->n_draws = 0; R->n_exact = 0; R->n_slow = 0; R->n_pass = 0; R->chain_cycles = 0; R->chain_wall = 0; }
     __syncthreads();
     if (tid == 0) R->phase_ticks[0] = (unsigned)(wall_clock64() - wall0);
+    if (tid < S) l.s_lab[tid] = (int)job.labels[l.s_sp[tid].lab_off];
     phase_copies(job, h, l.s_copy, tid, nt);
     if (tid == 0) R->phase_ticks[1] = (unsigned)(wall_clock64() - wall0);
-    if (upd) phase_update(job, h, l.s_sp, s_tab, tid, nt);
+    if (upd) phase_update(job, h, l.s_sp, l.s_lab, s_tab, tid, nt);
     if (tid == 0) R->phase_ticks[2] = (unsigned)(wall_clock64() - wall0);
     if (Rn <= 0 || S <= 0 || h.mode != MODE_HARD) { finish_level(h, R, wall0, tid); return; }
     phase_slots(job, h, tid, nt);
@@ -878,20 +887,34 @@ __global__ __launch_bounds__(512) void k_level(LevelBatch batch) {
     __syncthreads();
     if (tid == 0) R->phase_ticks[4] = (unsigned)(wall_clock64() - wall0);
     if (!h.any_multi) {
-        // thread (s, b): responsibilities summed in draw-slot order, as the reference adds them
-        for (int idx = tid; idx < S * (K + 1); idx += nt) {
-            const int s = idx / (K + 1), b = idx % (K + 1);
+        // One wavefront per strain: lane j adds the responsibilities of the slots j, j + 64, ... (in slot order), per read
+        // symbol, then the 64 partial sums are joined by a tree of fixed shape.  The reference adds them one after the other
+        // in long double; any fixed order of fp64 additions is as close to that as another (1e-13 relative, the tests allow
+        // 1e-9), and two candidates with equal inputs still get bitwise equal sums, which is what their ties rest on.
+        const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+        for (int s = wv; s < S; s += nw) {
             const double* prow = job.tabA + (long)s * job.qcap;
-            double acc = 0;
-            if (b == K) {
-#pragma unroll 8
-                for (int q = 0; q < Q; q++) acc += prow[q];
-                R->abund[s] = acc;
-            } else {
-#pragma unroll 8
-                for (int q = 0; q < Q; q++) acc += (job.qcode[q] == b) ? prow[q] : 0.0;
-                const int a = job.labels[l.s_sp[s].lab_off];
-                s_tab[s * K2 + a * K + b] = acc;
+            double acc[KMAX + 1];
+#pragma unroll
+            for (int b = 0; b <= KMAX; b++) acc[b] = 0.0;
+            for (int q = lane; q < Q; q += 64) {
+                const double p = prow[q];
+                const int code = job.qcode[q];
+                acc[KMAX] += p;
+#pragma unroll
+                for (int b = 0; b < KMAX; b++) acc[b] += (code == b) ? p : 0.0;
+            }
+#pragma unroll
+            for (int b = 0; b <= KMAX; b++) {
+                double v = acc[b];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+                acc[b] = v;
+            }
+            if (lane == 0) {
+                R->abund[s] = acc[KMAX];
+                const int a = l.s_lab[s];
+                if (a < K)
+                    for (int b = 0; b < K; b++) s_tab[s * K2 + a * K + b] = acc[b];
             }
         }
     } else {

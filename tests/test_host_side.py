@@ -314,3 +314,14 @@ def test_native_ingest_equals_python_mirror(seed, tmp_path):
         assert got.n_input == len(py.view(mq, 1804, roi))
         n_checked += len(exp)
     assert n_checked > 200
+
+
+def test_add_ones_equals_the_literal_loop(tmp_path):
+    """The urn update `a[c] += 1` per draw (NonparametricClustering.cpp:195) in O(log k): tests/native/add_ones_check.cpp
+    compares sc_add_ones with the literal long double loop around every binade border and at random."""
+    exe = str(tmp_path / "add_ones_check")
+    subprocess.check_call(["g++", "-O1", "-o", exe, os.path.join(ROOT, "tests", "native", "add_ones_check.cpp"),
+                           "-L" + os.path.join(ROOT, "rambl_amd"), "-lstraincall_hip", "-Wl,-rpath," + os.path.join(ROOT, "rambl_amd")])
+    p = subprocess.run([exe], stdout=subprocess.PIPE)
+    assert p.returncode == 0, p.stdout.decode()
+    assert b" 0 differences" in p.stdout

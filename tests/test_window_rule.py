@@ -1,8 +1,10 @@
-"""CPU model of the sampler's window rule (rambl_amd/csrc/sc_kernels.hip, urn_chain_q): a draw
-evaluated in fp32 with the counts in front of the window, p draws earlier, is final when no boundary
-lies within eps*T + p of u*T.  The model runs that rule with numpy fp32 arithmetic next to the plain
-sequential fp64 chain (the reference's order of draws) and checks that every accepted decision is the
-sequential one -- the property the device kernel relies on."""
+"""CPU model of the sampler's window rule (rambl_amd/csrc/sc_kernels.hip, urn_chain_q): a draw evaluated in fp32
+with the counts in front of the window, p draws earlier, is final when no boundary above the target u*T lies within
+eps*T + u*p of it and none below it within eps*T + (1-u)*p: each earlier draw adds L <= 1 to one count, which moves
+cum_s - u*T up by at most (1-u) and down by at most u.  The model runs that rule with numpy fp32 arithmetic next to
+the plain sequential fp64 chain (the reference's order of draws) and checks that every accepted decision is the
+sequential one -- the property the device kernel relies on -- and that it accepts more draws per pass than the
+symmetric rule (margin eps*T + p on both sides) it replaced."""
 import numpy as np
 import pytest
 
@@ -21,7 +23,7 @@ def sequential_chain(a0, L, u):
     return out
 
 
-def windowed_chain(a0, L, u, width=64):
+def windowed_chain(a0, L, u, width=64, one_sided=True):
     """The device rule in fp32; returns (decisions, passes, fallbacks)."""
     Q, S = L.shape
     Lf = L.astype(np.float32)
@@ -47,9 +49,18 @@ def windowed_chain(a0, L, u, width=64):
             tgt = np.float32(np.float32(u[t + p]) * T)
             d = (cum[:-1] - tgt).astype(np.float32)
             c = int(np.sum(d < 0))
-            dmin = np.float32(np.min(np.abs(d))) if S > 1 else np.float32(1e30)
-            lim = np.float32(eps * T + np.float32(p) + np.float32(1e-37))
-            if not (dmin >= lim):
+            if one_sided:
+                uf = np.float32(u[t + p])
+                up = np.float32(np.min(d[d >= 0])) if np.any(d >= 0) else np.float32(np.inf)     # nearest boundary at / above the target
+                dn = np.float32(np.min(-d[d < 0])) if np.any(d < 0) else np.float32(np.inf)      # nearest one below it
+                pf = np.float32(p) + np.float32(1e-37)
+                lim_up = np.float32(uf * pf + np.float32(eps * T))
+                lim_dn = np.float32((np.float32(1) - uf) * pf + np.float32(eps * T))
+                ok = (dn >= lim_dn) and (up >= lim_up)
+            else:
+                dmin = np.float32(np.min(np.abs(d))) if S > 1 else np.float32(1e30)
+                ok = dmin >= np.float32(eps * T + np.float32(p) + np.float32(1e-37))
+            if not ok:
                 adv = p
                 break
             cs[p] = c
@@ -87,3 +98,7 @@ def test_window_rule_reproduces_the_sequential_chain(seed):
     got, passes, fallbacks = windowed_chain(a0, L, u)
     assert np.array_equal(got, exp)
     assert passes < n_draws                                  # the window does accept several draws per pass
+    got128, passes128, _ = windowed_chain(a0, L, u, width=128)
+    assert np.array_equal(got128, exp)
+    old, passes_old, _ = windowed_chain(a0, L, u, one_sided=False)
+    assert np.array_equal(old, exp) and passes <= passes_old    # never fewer draws per pass than the symmetric margin
