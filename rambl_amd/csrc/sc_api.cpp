@@ -544,6 +544,18 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     }
     { int qo = 0; for (int i = 0; i < n_reads; i++) { ent_qoff[final_e0 + i] = qo; qo += job.reads[i].cn; } }
     const long qcap = std::max<long>(std::max<long>(max_level_q, total_copies), 1);
+    // cells of a read_loglik row that can hold a value when level l starts: the reads of the levels before it and their
+    // mates (the soft update enters a mate the first time it is asked for, Strain.cpp:147-150) -- a prefix of the read ids
+    std::vector<int> level_hi((size_t)f.n_levels + 1, 0);
+    for (int l = 0; l < f.n_levels; l++) {
+        int hi = level_hi[(size_t)l];
+        for (int x = f.level_ent_ptr[l]; x < f.level_ent_ptr[l + 1]; x++) {
+            const int rid = f.ent_rid[x];
+            hi = std::max(hi, rid + 1);
+            for (int k = job.mate_off[(size_t)rid]; k < job.mate_off[(size_t)rid + 1]; k++) hi = std::max(hi, job.mate_idx[(size_t)k] + 1);
+        }
+        level_hi[(size_t)l + 1] = hi;
+    }
 
     // ---- upload the static arrays
     JobDev jd{};
@@ -662,6 +674,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
 
     double t_last_done = now_ms();
     FILE* level_log = getenv("SC_LEVEL_LOG") ? fopen((std::string(getenv("SC_LEVEL_LOG")) + "." + std::to_string(slot)).c_str(), "a") : nullptr;   // diagnostics only
+    int cur_level = 0;
     auto run_level = [&](int mode, int e0, int e1, int Q, int n_sweeps, bool do_update, const std::vector<HStrain>& sv,
                          bool has_dups, bool any_multi) {
         LevelParams& P = *Ph;
@@ -670,6 +683,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         H.mode = mode; H.S = S; H.e0 = e0; H.e1 = e1; H.has_dups = has_dups; H.any_multi = any_multi; H.Q = Q;
         H.n_sweeps = n_sweeps; H.do_update = do_update ? 1 : 0;
         H.n_copy = (int)pending_copies.size();
+        H.copy_n = do_update ? level_hi[(size_t)cur_level] : n_reads;
         for (int c = 0; c < H.n_copy; c++) { P.copy_src[c] = pending_copies[c].first; P.copy_dst[c] = pending_copies[c].second; }
         pending_copies.clear();
         ld za = 0;
@@ -782,6 +796,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         }
         const int e0 = f.level_ent_ptr[level], e1 = f.level_ent_ptr[level + 1];
         const int Rn = e1 - e0;
+        cur_level = level;
         if (Rn > 0 && !level_strains.empty()) {
             const int S = (int)level_strains.size();
             if (S > MAXS) throw ScError(SC_ERR_CAPACITY, "more than 128 candidate strains at one level");
@@ -1081,10 +1096,10 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
     if (stream_count > 256) stream_count = 256;
     {
         const char* e = getenv("SC_LAUNCH_STREAMS");
-        int nl = e ? atoi(e) : 12;
+        int nl = e ? atoi(e) : 11;
         nl = nl < 1 ? 1 : (nl > 30 ? 30 : nl);
         if (nl > stream_count) nl = stream_count;
-        const int nset = stream_count > 1 ? 2 : 1;
+        const int nset = stream_count >= 8 ? 4 : (stream_count > 1 ? 2 : 1);      // 11 + 4 + the null stream = 16 hardware queues
         ctx->lstreams.resize((size_t)nl);
         ctx->setup_streams.resize((size_t)nset);
         bool ok = true;

@@ -60,6 +60,7 @@ struct LevelHdr {
     int n_copy;                  // row copies to perform first
     int do_update;               // apply the level's read log-likelihood update (not for read_assign)
     int done;                    // LV_* pieces already run by grid kernels (very large levels only)
+    int copy_n;                  // leading cells of a row that can hold a value yet (reads and mates met so far): what a row copy moves
     unsigned seq;                // completion stamp the kernel stores into LevelResult::seq when it is done
 };
 struct StrainParam {

@@ -277,7 +277,7 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelHdr& h
                                             const float* s_a0f, unsigned* s_cnt, int* s_x, float* s_uwin, const float* rows_lds, int stride, int tid) {
     constexpr int SPL = 4 * NQ, SP = 16 * NQ;               // strains per lane, capacity
     constexpr int NPLC = SP > 64 ? 2 : 1;                  // strains per lane in the checked tier
-    constexpr float EPSW = (float)(SP + 12) * 1.5e-7f;
+    constexpr float EPSW = (float)(SP + 16) * 1.5e-7f;     // (2*S + 9) * 2^-24 for the chains and sums + 3 * 2^-24 for the weights (exp_weight)
     const int lane = tid & 63, wv = tid >> 6, k = lane & 3, pos = wv * 16 + (lane >> 2);
     const int S = h.S, Q = h.Q, n = h.n_sweeps, e0 = h.e0;
     const int Sm1 = S - 1;
@@ -529,7 +529,7 @@ __device__ __forceinline__ void phase_copies(const JobDev& job, const LevelHdr& 
     for (int c = 0; c < ((h.done & LV_COPIES_DONE) ? 0 : h.n_copy); c++) {
         const double2* src = reinterpret_cast<const double2*>(job.ll + (long)s_copy[c] * stride);
         double2* dst = reinterpret_cast<double2*>(job.ll + (long)s_copy[MAXS + c] * stride);
-        const int n2 = (job.n_reads + 1) >> 1;
+        const int n2 = ((h.copy_n < job.n_reads ? h.copy_n : job.n_reads) + 1) >> 1;      // cells past copy_n hold nothing yet
         int i = tid;
         for (; i + 3 * nt < n2; i += 4 * nt) {        // four independent 16-byte loads in flight per thread
             const double2 v0 = src[i], v1 = src[i + nt], v2 = src[i + 2 * nt], v3 = src[i + 3 * nt];
@@ -670,6 +670,20 @@ __device__ __forceinline__ void finish_level(const LevelHdr& h, LevelResult* __r
     }
 }
 
+// exp(y), y <= 0, as an fp32 sampler weight: y = k ln2 + r in fp64 (exact to 2^-60), exp(r) by the fp32 hardware
+// exponential, scaled by 2^k.  Relative error < 3 * 2^-24 (fp32 rounding of r: 0.35 * 2^-25; of r * log2 e: 0.5 * 2^-24;
+// v_exp_f32: 1 ulp; the final rounding), which the window margin EPSW budgets for; a NaN stays a NaN (it sends the
+// draw to the checked tiers), anything below 2^-149 is 0 as in the rounded exact value.
+__device__ __forceinline__ float exp_weight(double y) {
+    if (y < -104.0) return 0.0f;                              // below the last fp32 denormal (and -inf: log 0)
+    const double k = rint(y * 1.4426950408889634);
+    double r = fma(k, -0.693147180559945286, y);
+    r = fma(k, -2.3190468138462996e-17, r);
+    const float e = __builtin_amdgcn_exp2f((float)r * 1.44269504f);
+    const double kc = fmax(k, -300.0);                        // ldexpf's int: far below the last denormal is still 0
+    return (y == y) ? ldexpf(e, (int)kc) : __int_as_float(0x7fc00000);
+}
+
 __host__ __device__ inline int chain_w_stride(int S) {
     const int s4 = (S + 1 + 3) & ~3;                          // S weights + the read symbol
     return (s4 & 4) ? s4 : s4 + 4;                            // 4 * odd: conflict-free 16-byte row reads
@@ -792,7 +806,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(LevelBatch batch
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const int sx = s0 + i;
-                    if (sx < s1) put(Lf + sx, flag ? __int_as_float(0x7fc00000) : (float)exp(x[i] - m));
+                    if (sx < s1) put(Lf + sx, flag ? __int_as_float(0x7fc00000) : exp_weight(x[i] - m));
                 }
                 if (g == 0) {
                     // the read symbol rides behind the weights (a tiny denormal under a zero count: no effect on the sums)
