@@ -194,3 +194,49 @@ def oracle_msa(seqs):
     assert rc == 0
     w = ncol.value + 1
     return [out.raw[i * w:i * w + ncol.value].decode() for i in range(len(seqs))]
+
+
+def write_bam(sam_path, bam_path):
+    """Minimal BAM writer (SAM spec section 4) used only to exercise the native reader."""
+    import struct
+    import zlib
+    hdr, recs, refs = [], [], []
+    for line in open(sam_path):
+        if line.startswith("@"):
+            hdr.append(line)
+            if line.startswith("@SQ"):
+                f = dict(x.split(":", 1) for x in line.rstrip().split("\t")[1:])
+                refs.append((f["SN"], int(f["LN"])))
+        elif line.strip():
+            recs.append(line.rstrip("\n").split("\t"))
+    ref_id = {n: i for i, (n, _) in enumerate(refs)}
+    text = "".join(hdr).encode()
+    out = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs)))
+    for n, l in refs:
+        out += struct.pack("<i", len(n) + 1) + n.encode() + b"\x00" + struct.pack("<i", l)
+    seq_code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    cig_code = {c: i for i, c in enumerate("MIDNSHP=X")}
+    import re
+    for f in recs:
+        qn = f[0].encode() + b"\x00"
+        cig = [(int(n), op) for n, op in re.findall(r"(\d+)([MIDNSHP=X])", f[5])]
+        seq = f[9]
+        sb = bytearray()
+        for k in range(0, len(seq), 2):
+            hi = seq_code[seq[k]]
+            lo = seq_code[seq[k + 1]] if k + 1 < len(seq) else 0
+            sb.append(hi << 4 | lo)
+        qual = bytes(ord(c) - 33 for c in f[10]) if f[10] != "*" else b"\xff" * len(seq)
+        body = struct.pack("<iiBBHHHiiii", ref_id.get(f[2], -1), int(f[3]) - 1, len(qn), int(f[4]), 0, len(cig), int(f[1]),
+                           len(seq), -1, -1, 0)
+        body += qn + b"".join(struct.pack("<I", n << 4 | cig_code[op]) for n, op in cig) + bytes(sb) + qual
+        out += struct.pack("<i", len(body)) + body
+    with open(bam_path, "wb") as g:
+        for k in range(0, len(out), 60000):          # BGZF: gzip members with the BC extra field
+            chunk = bytes(out[k:k + 60000])
+            comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+            cdata = comp.compress(chunk) + comp.flush()
+            bsize = len(cdata) + 25
+            g.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize)
+                    + cdata + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+        g.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))

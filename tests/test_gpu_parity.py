@@ -440,3 +440,16 @@ def test_config4_million_reads_match_reference(depth, million_reads):
     assert _sha(fa) == meta["fasta_sha256"] and _sha(sam) == meta["sam_sha256"]
     got = T.run_product(meta["argv"] + [fa, sam])
     assert got == open(os.path.join(gold, "expected.fa")).read()
+
+
+@pytest.mark.parametrize("seed", [2, 6])
+def test_region_from_bam_matches_oracle(seed, tmp_path, oracle_bin, monkeypatch):
+    """BAM in (read by the library's own BGZF / BAM decoder: no samtools in the image), FASTA out: equal to the oracle
+    on the SAM text the BAM was written from (paired reads; several scan windows)."""
+    monkeypatch.setenv("SC_NATIVE_BAM", "1")
+    d = str(tmp_path)
+    args = T.make_case(seed, d)
+    exp_fa, _ = T.run_oracle(args, d)
+    bam = os.path.join(d, "reads.bam")
+    T.write_bam(args[-1], bam)
+    assert T.run_product(args[:-1] + [bam]) == exp_fa

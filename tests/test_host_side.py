@@ -163,52 +163,6 @@ def test_pileup_flags_equal_pileup_text(seed, tmp_path):
             assert aln.pileup_flags(mq, region) == samio.flags_from_pileup_text(aln.mpileup(mq, region))
 
 
-def _write_bam(sam_path, bam_path):
-    """Minimal BAM writer (SAM spec section 4) used only to exercise the native reader."""
-    import struct
-    import zlib
-    hdr, recs, refs = [], [], []
-    for line in open(sam_path):
-        if line.startswith("@"):
-            hdr.append(line)
-            if line.startswith("@SQ"):
-                f = dict(x.split(":", 1) for x in line.rstrip().split("\t")[1:])
-                refs.append((f["SN"], int(f["LN"])))
-        elif line.strip():
-            recs.append(line.rstrip("\n").split("\t"))
-    ref_id = {n: i for i, (n, _) in enumerate(refs)}
-    text = "".join(hdr).encode()
-    out = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs)))
-    for n, l in refs:
-        out += struct.pack("<i", len(n) + 1) + n.encode() + b"\x00" + struct.pack("<i", l)
-    seq_code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
-    cig_code = {c: i for i, c in enumerate("MIDNSHP=X")}
-    import re
-    for f in recs:
-        qn = f[0].encode() + b"\x00"
-        cig = [(int(n), op) for n, op in re.findall(r"(\d+)([MIDNSHP=X])", f[5])]
-        seq = f[9]
-        sb = bytearray()
-        for k in range(0, len(seq), 2):
-            hi = seq_code[seq[k]]
-            lo = seq_code[seq[k + 1]] if k + 1 < len(seq) else 0
-            sb.append(hi << 4 | lo)
-        qual = bytes(ord(c) - 33 for c in f[10]) if f[10] != "*" else b"\xff" * len(seq)
-        body = struct.pack("<iiBBHHHiiii", ref_id.get(f[2], -1), int(f[3]) - 1, len(qn), int(f[4]), 0, len(cig), int(f[1]),
-                           len(seq), -1, -1, 0)
-        body += qn + b"".join(struct.pack("<I", n << 4 | cig_code[op]) for n, op in cig) + bytes(sb) + qual
-        out += struct.pack("<i", len(body)) + body
-    with open(bam_path, "wb") as g:
-        for k in range(0, len(out), 60000):          # BGZF: gzip members with the BC extra field
-            chunk = bytes(out[k:k + 60000])
-            comp = zlib.compressobj(6, zlib.DEFLATED, -15)
-            cdata = comp.compress(chunk) + comp.flush()
-            bsize = len(cdata) + 25
-            g.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize)
-                    + cdata + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
-        g.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
-
-
 @pytest.mark.parametrize("seed", [2, 4])
 def test_native_bam_reader_gives_the_same_regions(seed, tmp_path, monkeypatch):
     """BAM input read natively (no samtools in the image) yields the same ingest as the SAM text."""
@@ -216,7 +170,7 @@ def test_native_bam_reader_gives_the_same_regions(seed, tmp_path, monkeypatch):
     d = str(tmp_path)
     args = T.make_case(seed, d)
     bam = os.path.join(d, "reads.bam")
-    _write_bam(args[-1], bam)
+    T.write_bam(args[-1], bam)
     from rambl_amd import samio
     assert samio.is_bam(bam)
     a = cli.load_regions(cli.parse_cmd_line(args))
@@ -325,3 +279,74 @@ def test_add_ones_equals_the_literal_loop(tmp_path):
     p = subprocess.run([exe], stdout=subprocess.PIPE)
     assert p.returncode == 0, p.stdout.decode()
     assert b" 0 differences" in p.stdout
+
+
+def _bgzf_block(payload):
+    """One BGZF block exactly as SAM specification section 4.1 lays it out (gzip member, FEXTRA with the BC subfield)."""
+    import struct
+    import zlib
+    comp = zlib.compressobj(9, zlib.DEFLATED, -15)
+    cdata = comp.compress(payload) + comp.flush()
+    bsize = len(cdata) + 25                                   # total block size - 1
+    return (b"\x1f\x8b\x08\x04" + b"\x00\x00\x00\x00" + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<H", 2) +
+            struct.pack("<H", bsize) + cdata + struct.pack("<I", zlib.crc32(payload) & 0xFFFFFFFF) + struct.pack("<I", len(payload)))
+
+
+def test_bam_decoder_on_hand_assembled_bytes(tmp_path):
+    """The library's BGZF/BAM decoder (sc_aln_open) on bytes assembled field by field from the SAM specification (section
+    4.2: block_size, refID, pos, l_read_name, mapq, bin, n_cigar_op, flag, l_seq, next_refID, next_pos, tlen, read_name,
+    cigar as oplen<<4|op, 4-bit packed seq over '=ACMGRSVTWYHKDBN', qual) -- not by any BAM writer of this repository:
+    records that straddle BGZF block borders, an empty block in the middle, = and X and N and H and P operations, an odd
+    l_seq, a 0xff quality string, an unmapped mate (flag 73) and a fully unmapped read (refID -1).  The expected SAM fields
+    are written out by hand below; the Python reader (samio.bam_records, gzip module) must agree too."""
+    import struct
+    from rambl_amd import capi, samio
+
+    def rec(ref_id, pos0, name, mapq, cigar_ops, flag, seq_nibbles, l_seq, qual, next_ref=-1, next_pos=-1, tlen=0):
+        body = struct.pack("<iiBBHHHiiii", ref_id, pos0, len(name) + 1, mapq, 4680, len(cigar_ops), flag, l_seq, next_ref, next_pos, tlen)
+        body += name + b"\x00" + b"".join(struct.pack("<I", c) for c in cigar_ops) + seq_nibbles + qual
+        return struct.pack("<i", len(body)) + body
+
+    hdr_text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:otuA\tLN:50\n@SQ\tSN:otuB\tLN:40\n"
+    head = b"BAM\x01" + struct.pack("<i", len(hdr_text)) + hdr_text + struct.pack("<i", 2)
+    head += struct.pack("<i", 5) + b"otuA\x00" + struct.pack("<i", 50) + struct.pack("<i", 5) + b"otuB\x00" + struct.pack("<i", 40)
+    # r1: otuA pos 3, 2S 3= 1X 2I 1D 2M (7 aligned read bases + 2 clipped = 10 bases "TTACGTAACG"), flag 99, mate at otuA:30
+    r1 = rec(0, 2, b"r1", 42, [2 << 4 | 4, 3 << 4 | 7, 1 << 4 | 8, 2 << 4 | 1, 1 << 4 | 2, 2 << 4 | 0], 99,
+             bytes([0x88, 0x12, 0x48, 0x11, 0x24]), 10, bytes([40] * 10), 0, 29, 37)
+    # r2: otuA pos 10, 5M 4N 3M with hard clips and a pad: 2H 5M 4N 1P 3M 3H; 8 bases "GGGGGCCC"; odd length next: see r3
+    r2 = rec(0, 9, b"read/2", 0, [2 << 4 | 5, 5 << 4 | 0, 4 << 4 | 3, 1 << 4 | 6, 3 << 4 | 0, 3 << 4 | 5], 16,
+             bytes([0x44, 0x44, 0x42, 0x22]), 8, bytes([0xff] * 8))
+    # r3: otuB pos 1, 7M, 7 bases "ACGTNRY" (odd l_seq: the last low nibble is padding), mate unmapped (flag 73)
+    r3 = rec(1, 0, b"r3", 255, [7 << 4 | 0], 73, bytes([0x12, 0x48, 0xF5, 0xA0]), 7, bytes(range(7)), 1, 0, 0)
+    # r4: unmapped, no reference, no cigar, 4 bases "TTTT"
+    r4 = rec(-1, -1, b"r4", 0, [], 77, bytes([0x88, 0x88]), 4, bytes([30] * 4))
+    stream = head + r1 + r2 + r3 + r4
+    # block borders inside the header, inside r1's cigar, inside r2's name; one empty block; EOF marker block
+    cuts = [0, 17, len(head) + 44, len(head) + len(r1) + 40, len(stream)]
+    blob = b""
+    for a, b in zip(cuts, cuts[1:]):
+        blob += _bgzf_block(stream[a:b])
+        if a == 17:
+            blob += _bgzf_block(b"")
+    blob += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    path = str(tmp_path / "hand.bam")
+    open(path, "wb").write(blob)
+
+    expected = [
+        ["r1", "99", "otuA", "3", "42", "2S3=1X2I1D2M", "=", "30", "37", "TTACGTAACG", "I" * 10],
+        ["read/2", "16", "otuA", "10", "0", "2H5M4N1P3M3H", "*", "0", "0", "GGGGGCCC", "*"],
+        ["r3", "73", "otuB", "1", "255", "7M", "=", "1", "0", "ACGTNRY", "!\"#$%&'"],
+        ["r4", "77", "*", "0", "0", "*", "*", "0", "0", "TTTT", "????"],
+    ]
+    assert list(samio.bam_records(path)) == expected
+    aln = capi.NativeAln(path)
+    assert aln.records() == 4
+    assert aln.ref_stats("otuA") == (2, (3 + 1 + 1 + 2) + (5 + 4 + 3)) and aln.ref_stats("otuB") == (1, 7) and aln.ref_stats("*") == (1, 1)
+    # view semantics on them: -F 1804 drops r4 (unmapped) and keeps r1 (99), r2 (16), r3 (73: mate unmapped is bit 8 = filtered)
+    got = aln.load_reads("", "otuA", 1, 50, 0, 0, 13, 800)
+    assert got.n_input == 2
+    assert (got.pos, got.cigar, got.seq, got.copies) == ([2, 9], ["3M1M2I1D2M", "2H5M4N1P3M3H"], ["ACGTAACG", "GGGGGCCC"], [1, 1])
+    assert got.mates == [[-1], [-1]]                         # r1 -> "r1/1" (flag 99 has 65 set? 99 = 1+2+32+64: yes), mate "r1/2" absent
+    assert aln.load_reads("", "otuB", 1, 40, 0, 0, 13, 800).n_input == 0      # flag 73 & 1804 = 8: mate unmapped is filtered by -F 1804
+    # pileup: r1 covers 3-9 (insertion marked on the base before it, 6; deleted base 7), r2 covers 10-21 (skipped 15-18 read as '*')
+    assert aln.pileup_flags(0, "otuA", 1, 50) == {p: (p == 6, p == 7 or 15 <= p <= 18) for p in range(3, 22)}
