@@ -163,6 +163,29 @@ int sc_reads_get(sc_reads* reads, int* n_reads, const int** pos, const char** ci
                  const int** mate_off, long* n_input, int* depth);
 void sc_reads_free(sc_reads* reads);
 
+/* ---- rambl.py stage 1 on the device (rambl_amd/csrc/sc_depth.hip) --------------------------------------------
+ *
+ * /root/reference/scripts/coverage_all_samples.py:21-186 pipes `samtools depth <bams>` (per-base depth per file,
+ * deleted and skipped bases not counted, flags 0x704 excluded) through awk (sum over the files), sort and
+ * `bedtools merge -c 4 -o mean -d 10` (one-base records [p, p+1) merged while at most 10 uncovered bases separate
+ * them; mean of the merged depths).  sc_depth_scan does the same from alignment files the library has read:
+ * intervals come back sorted by (reference index, start), 1-based inclusive, with the sum of the depths of their
+ * covered positions and their number (mean = sum / n).  Returns SC_ERR_CAPACITY (with *n_intervals set) when `cap`
+ * is too small.  samtools' per-file depth cap (8000) is not applied; parity at that tool boundary is unpinned. */
+typedef struct sc_depth_stats {
+    long cells;            /* cells of the difference array (reference bases + padding) */
+    long runs;             /* aligned runs (CIGAR M = X operations) marked */
+    double mark_ms;        /* clearing the array + k_depth_mark, HIP events */
+    double segments_ms;    /* k_depth_segments, HIP events: streams 4 bytes per cell */
+} sc_depth_stats;
+int sc_depth_scan(int device, sc_aln* const* alns, int n_alns, const char* const* ref_names, const int* ref_len, int n_refs,
+                  int max_gap, int* iv_ref, int* iv_start, int* iv_end, long* iv_sum, int* iv_n, int cap, int* n_intervals,
+                  sc_depth_stats* stats);
+/* The same from bare runs: run i covers positions run_start[i]..run_end[i] (1-based, inclusive) of reference run_ref[i]. */
+int sc_depth_scan_runs(int device, const int* ref_len, int n_refs, const int* run_ref, const int* run_start, const int* run_end,
+                       long n_runs, int max_gap, int* iv_ref, int* iv_start, int* iv_end, long* iv_sum, int* iv_n, int cap,
+                       int* n_intervals, sc_depth_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

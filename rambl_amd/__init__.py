@@ -5,4 +5,4 @@ import os as _os
 # streams want one each.  HIP reads this once, when it initialises in the process.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
-__all__ = ["cli", "ingest", "samio", "synth", "capi", "stage5"]
+__all__ = ["cli", "ingest", "samio", "synth", "capi", "stage1", "stage5"]

@@ -83,7 +83,7 @@ def load_library():
 EXPORTS = ["sc_ctx_create", "sc_ctx_destroy", "sc_last_error", "sc_roi_submit", "sc_roi_wait", "sc_roi_result",
            "sc_roi_graph_dump", "sc_roi_trace", "sc_roi_stats", "sc_roi_release", "sc_roi_edge_support", "sc_msa_align",
            "sc_roi_thread_tables", "sc_aln_open", "sc_aln_close", "sc_aln_error", "sc_aln_records", "sc_aln_ref_stats", "sc_aln_pileup_flags",
-           "sc_aln_load_reads", "sc_reads_get", "sc_reads_free"]
+           "sc_aln_load_reads", "sc_reads_get", "sc_reads_free", "sc_depth_scan", "sc_depth_scan_runs"]
 
 
 def default_params(error_rate=0.01, tau=0.02, diff_rate=0.01, graph_only=False, want_trace=False, want_timing=False, want_graph=False):
