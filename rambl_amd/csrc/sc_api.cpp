@@ -224,7 +224,7 @@ struct Worker {
     DevBuf b_ent_rid, b_ent_cn, b_ent_lab_off, b_ent_lab_len, b_ent_first, b_ent_qoff, b_labels, b_mate_ptr, b_mate_idx,
         b_ll, b_has, b_isnew, b_tabA, b_tabLf, b_qcode, b_qent, b_quid, b_out_ptr, b_out_node, b_pool_ptr, b_pool_rid,
         b_pool_cn, b_isend, b_esrc, b_support;
-    DevBuf m_seqs, m_off, m_cols0, m_cols1, m_counts, m_moves, m_trace, m_out;
+    DevBuf m_seqs, m_off, m_cols0, m_cols1, m_counts, m_moves, m_trace, m_out, m_edge;
     DevBuf t_ref, t_pos, t_seqoff, t_seq, t_cigoff, t_cigop, t_ciglen, t_lut, t_tabs, t_pool, t_pool2;
 
     void init();
@@ -363,8 +363,8 @@ int Worker::msa_device(const std::vector<std::string>& seqs, std::vector<std::st
     std::string packed;
     for (int i = 0; i < n; i++) { packed += seqs[i]; off[i + 1] = (int)packed.size(); }
     const int cmax = (int)packed.size() + 1;
-    for (int i = 1; i < n; i++)
-        if (seqs[i].size() > 63) throw ScError(SC_ERR_UNSUPPORTED, "insertion longer than 63 bases in the MSA");
+    size_t longest = 0;                                   // (the first sequence only seeds the columns: any length)
+    for (int i = 1; i < n; i++) longest = std::max(longest, seqs[i].size());
     MsaDev d;
     char* dseq = (char*)m_seqs.ensure(packed.size() + 1);
     int* doff = (int*)m_off.ensure(sizeof(int) * (n + 1));
@@ -374,7 +374,9 @@ int Worker::msa_device(const std::vector<std::string>& seqs, std::vector<std::st
     d.cols[0] = (char*)m_cols0.ensure((size_t)cmax * n);
     d.cols[1] = (char*)m_cols1.ensure((size_t)cmax * n);
     d.counts = (int*)m_counts.ensure(sizeof(int) * 11 * (size_t)cmax);
-    d.moves = (uint8_t*)m_moves.ensure((size_t)(cmax + 1) * 64);
+    d.mv_stride = (int)((longest + 1 + 63) / 64) * 64;
+    d.moves = (uint8_t*)m_moves.ensure((size_t)(cmax + 1) * (size_t)d.mv_stride);
+    d.edge = (int*)m_edge.ensure(sizeof(int) * 2 * (size_t)(cmax + 1));
     d.trace = (int*)m_trace.ensure(sizeof(int) * 2 * (size_t)(cmax + 64));
     int* dout = (int*)m_out.ensure(sizeof(int) * 2);
     d.ncol_out = dout; d.err_out = dout + 1;

@@ -132,7 +132,9 @@ struct MsaDev {
     int cmax;               // capacity in columns
     char* cols[2];          // [cmax][n] column-major MSA, double buffered
     int* counts;            // [cmax][11] character-class counts of the current columns
-    uint8_t* moves;         // [(cmax+1)][64] traceback moves: 0 diag, 1 insert(left), 2 delete(up)
+    uint8_t* moves;         // [(cmax+1)][mv_stride] traceback moves: 0 diag, 1 insert(left), 2 delete(up)
+    int mv_stride;          // DP columns per row of `moves`: 64 while every sequence has at most 63 bases
+    int* edge;              // [2][cmax+1] last DP column of a 64-column chunk, for sequences longer than 63
     int* trace;             // [2*cmax] traceback script
     int* ncol_out;
     int* err_out;

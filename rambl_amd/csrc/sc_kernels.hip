@@ -1031,17 +1031,23 @@ __global__ __launch_bounds__(256) void k_msa(MsaDev d) {
         const char* seq = d.seqs + d.seq_off[t];
         const int len = d.seq_off[t + 1] - d.seq_off[t];
         const int nn = len + 1;
-        if (nn > 64 || ncol + len > CM || ncol + len > d.cmax) {
-            if (tid == 0) s_err = (nn > 64 ? 1 : 0) | (ncol + len > CM ? 2 : 0) | (ncol + len > d.cmax ? 4 : 0);
+        const int mvs = WIDE ? d.mv_stride : 64;          // DP columns the traceback table holds per row
+        if (nn > mvs || ncol + len > CM || ncol + len > d.cmax) {
+            if (tid == 0) s_err = (nn > mvs ? 1 : 0) | (ncol + len > CM ? 2 : 0) | (ncol + len > d.cmax ? 4 : 0);
             __syncthreads();
             break;
         }
         const char* colc = d.cols[cur];
         const unsigned short* cntc = s_cnt + (size_t)cur * CM * 10;
         const char* c0c = s_c0 + (size_t)cur * CM;
-        // ---- forward, wave 0: lane j = DP column j, time step tau handles row i = tau - j
-        if (tid < 64) {
-            const int j = lane;
+        // ---- forward, wave 0: lane l = DP column j = 64 * chunk + l, time step tau handles row i = tau - l.  A sequence of
+        // more than 63 bases takes several chunks of 64 columns, one after the other; the last column of a chunk leaves its
+        // cells in `edge` (row by row), where lane 0 of the next chunk finds its left and diagonal neighbours
+        if (tid < 64)
+        for (int chunk = 0; chunk * 64 < nn; chunk++) {
+            const int j = chunk * 64 + lane;
+            const bool more = (chunk + 1) * 64 < nn;          // another chunk follows: record the last column
+            int* edge = WIDE ? d.edge : nullptr;              // [2][m]: score, state of the cells (i, 64 * chunk - 1)
             const int b = (j >= 1 && j < nn) ? cls_of(seq[j - 1]) : 10;
             int scb[9];
 #pragma unroll
@@ -1052,11 +1058,14 @@ __global__ __launch_bounds__(256) void k_msa(MsaDev d) {
             // row 0: SC[0][j] = s*(-6) + (j-1)*s*(-2), state ins for j >= 1, mat at j = 0
             if (j >= 1) { sc_up = s * (-6) + (j - 1) * s * (-2); st_up = 1; }
             int sc_left_prev = 0, st_left_prev = 0;   // cell (i-1, j-1) as delivered last step
-            for (int tau = 1; tau < m + nn - 1; tau++) {
-                const int i = tau - j;
-                // values of cell (i, j-1) computed by lane j-1 in the previous step
-                const int sc_l = __shfl_up(sc_up, 1);      // lane j-1's current (i, j-1) sits in its sc_up
-                const int st_l = __shfl_up(st_up, 1);
+            if (chunk > 0 && lane == 0) { sc_left_prev = s * (-6) + (j - 2) * s * (-2); st_left_prev = 1; }     // cell (0, j-1)
+            const int width = (nn - chunk * 64 < 64) ? nn - chunk * 64 : 64;      // DP columns of this chunk
+            for (int tau = 1; tau < m + width - 1; tau++) {
+                const int i = tau - lane;
+                // values of cell (i, j-1) computed by lane l-1 in the previous step (lane 0 of a later chunk: by the chunk before)
+                int sc_l = __shfl_up(sc_up, 1);            // lane l-1's current (i, j-1) sits in its sc_up
+                int st_l = __shfl_up(st_up, 1);
+                if (WIDE && chunk > 0 && lane == 0 && i < m) { sc_l = edge[i]; st_l = edge[d.cmax + 1 + i]; }
                 int sc_new = sc_up, st_new = st_up;
                 if (i >= 1 && i < m && j < nn) {
                     const unsigned short* cnt = cntc + (i - 1) * 10;
@@ -1085,8 +1094,9 @@ __global__ __launch_bounds__(256) void k_msa(MsaDev d) {
                         if (r1 >= r2 && r1 >= r3) { sc_new = r1; st_new = (c0 == '-') ? 1 : 0; mv = 0; }
                         else if (r2 >= r1 && r2 >= r3) { sc_new = r2; st_new = 1; mv = 1; }
                         else { sc_new = r3; st_new = (c0 == '-') ? 0 : 2; mv = 2; }
-                        s_mv[(size_t)i * 64 + j] = mv;
+                        s_mv[(size_t)i * mvs + j] = mv;
                     }
+                    if (WIDE && more && lane == 63) { edge[i] = sc_new; edge[d.cmax + 1 + i] = st_new; }     // read 63 steps ago by this chunk's lane 0
                 }
                 // what lane j-1 held BEFORE this step is cell (i-1, j-1) for the next step
                 sc_left_prev = sc_l; st_left_prev = st_l;
@@ -1100,7 +1110,7 @@ __global__ __launch_bounds__(256) void k_msa(MsaDev d) {
             int r1 = ncol - 1, r2 = len - 1;
             while (!(x == 0 && y == 0)) {
                 int mv;
-                if (x == 0) mv = 1; else if (y == 0) mv = 2; else mv = s_mv[(size_t)x * 64 + y];
+                if (x == 0) mv = 1; else if (y == 0) mv = 2; else mv = s_mv[(size_t)x * mvs + y];
                 if (mv == 0) { s_trace[2 * cnt] = r1; s_trace[2 * cnt + 1] = r2; --r1; --r2; --x; --y; }
                 else if (mv == 1) { s_trace[2 * cnt] = -1; s_trace[2 * cnt + 1] = r2; --r2; --y; }
                 else { s_trace[2 * cnt] = r1; s_trace[2 * cnt + 1] = -1; --r1; --x; }
@@ -1350,7 +1360,7 @@ void launch_level_batch(hipStream_t st, int kind, const LevelBatch& b, int n) {
 #undef SC_SAMPLE
 }
 void launch_msa(hipStream_t st, const MsaDev& d) {
-    if (d.cmax > MSA_CM) hipLaunchKernelGGL(k_msa<true>, dim3(1), dim3(256), 0, st, d);      // state in HBM scratch
+    if (d.cmax > MSA_CM || d.mv_stride > 64) hipLaunchKernelGGL(k_msa<true>, dim3(1), dim3(256), 0, st, d);      // state in HBM scratch
     else hipLaunchKernelGGL(k_msa<false>, dim3(1), dim3(256), MSA_LDS, st, d);
 }
 // a5 in four launches; `pool_sorted` receives the class pools in read order.

@@ -316,8 +316,8 @@ def test_msa_kernel_wider_than_lds(oracle_bin):
 
 
 def test_msa_kernel_deep_and_long(oracle_bin):
-    """k_msa with hundreds of rows (deep coverage at an indel hot spot) and with insertions up to
-    the 63-base limit of the one-wavefront DP."""
+    """k_msa with hundreds of rows (deep coverage at an indel hot spot) and with insertions shorter and longer than the
+    64 DP columns one pass of the wavefront holds."""
     import time
     from rambl_amd import capi
     rng = random.Random(17)
@@ -348,8 +348,13 @@ def test_msa_kernel_deep_and_long(oracle_bin):
         seqs = ["".join(rng.choice("ACGT") for _ in range(rng.choice([63, 40, 17, 5, 2]))) for _ in range(12)]
         seqs.sort(key=len, reverse=True)
         assert ctx.msa_align(seqs) == T.oracle_msa(seqs)
-        with pytest.raises(capi.StrainCallError):
-            ctx.msa_align(["A" * 10, "C" * 64])       # second sequence longer than 63: reported, not guessed
+        # insertions of 64 bases and more (-I is the user's to raise): the DP columns run in chunks of 64 lanes
+        for lens in ([64, 10], [65, 64, 63, 3], [200, 130, 129, 128, 127, 64, 1], [300, 299, 7, 7, 2]):
+            seqs = ["".join(rng.choice("ACGT") for _ in range(n)) for n in lens]
+            assert ctx.msa_align(seqs) == T.oracle_msa(seqs), lens
+        related = "".join(rng.choice("ACGT") for _ in range(150))
+        seqs = sorted([related, related[:100] + "TT" + related[100:], related[5:140], related[:70] + related[75:]], key=len, reverse=True)
+        assert ctx.msa_align(seqs) == T.oracle_msa(seqs)
 
 
 @pytest.mark.parametrize("seed", [3, 16, 31])
