@@ -727,8 +727,28 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         H.seq = ++seq;
         level_want = H.seq;
         const double t_launched = level_log ? now_ms() : 0.0;
-        ctx->submit_level(LevelRequest{this, LevelItem{jd, H, Pm, Rd}, level_kind(H), timed});
-        wait_level();
+        if (ctx->workers.size() == 1) {
+            // a single region in flight: nobody to batch with, so the worker launches its level itself and watches the stamp
+            LevelBatch batch;
+            batch.it[0] = LevelItem{jd, H, Pm, Rd};
+            hipStream_t ls = ctx->lstreams[0].st;
+            if (timed) HIPCHK(hipEventRecord(ev0, ls));
+            launch_level_batch(ls, level_kind(H), batch, 1);
+            if (timed) HIPCHK(hipEventRecord(ev1, ls));
+            t_batch_launched = level_log ? now_ms() : 0.0; batch_n = 1;
+            unsigned spins = 0;
+            while (__atomic_load_n(&Rh->seq, __ATOMIC_ACQUIRE) != H.seq) {
+                __builtin_ia32_pause();
+                if ((++spins & 0x3FFFFu) == 0) {             // every few milliseconds: has the stream died?
+                    const hipError_t e = hipStreamQuery(ls);
+                    if (e == hipSuccess) { if (__atomic_load_n(&Rh->seq, __ATOMIC_ACQUIRE) != H.seq) throw HipError("a level kernel ended without its completion stamp"); }
+                    else if (e != hipErrorNotReady) throw HipError(std::string("level kernel: ") + hipGetErrorString(e));
+                }
+            }
+        } else {
+            ctx->submit_level(LevelRequest{this, LevelItem{jd, H, Pm, Rd}, level_kind(H), timed});
+            wait_level();
+        }
         if (timed) HIPCHK(hipEventSynchronize(ev1));
         level_launches++;
         if (chain) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 outputs of `bench.py` into the files kept under profiles/rNN/.
 
-    python3 tools/summarize_profiles.py STATS_DIR FETCH_DIR WRITE_DIR OUT_DIR
+    python3 tools/summarize_profiles.py STATS_DIR FETCH_DIR WRITE_DIR OUT_DIR [TAG]
 
 STATS_DIR: `rocprofv3 --kernel-trace --stats --output-format csv` run; FETCH_DIR / WRITE_DIR: separate
 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs (`--kernel-trace --output-format csv`).  Writes
@@ -31,7 +31,13 @@ def counter_avgs(path, counter):
             if row.get("Counter_Name") != counter:
                 continue
             name = row["Kernel_Name"]
-            key = "k_chain_w" if "k_chain_w" in name else ("k_level" if "sc::k_level(" in name else None)
+            key = None
+            for fam in ("k_level_sample", "k_depth_segments", "k_depth_mark", "k_level_copy", "k_level_update"):
+                if fam in name:
+                    key = fam
+                    break
+            if key is None and "sc::k_level(" in name:
+                key = "k_level"
             if key is None:
                 continue
             n, tot = per.get(key, (0, 0.0))
@@ -41,28 +47,29 @@ def counter_avgs(path, counter):
 
 def main():
     stats_dir, fetch_dir, write_dir, out = sys.argv[1:5]
+    tag = sys.argv[5] if len(sys.argv) > 5 else "bench_config2"
     os.makedirs(out, exist_ok=True)
-    shutil.copy(find(stats_dir, "_kernel_stats.csv"), os.path.join(out, "bench_config2_kernel_stats.csv"))
-    with open(find(stats_dir, "_kernel_trace.csv"), "rb") as f, gzip.open(os.path.join(out, "bench_config2_kernel_trace.csv.gz"), "wb") as g:
+    shutil.copy(find(stats_dir, "_kernel_stats.csv"), os.path.join(out, tag + "_kernel_stats.csv"))
+    with open(find(stats_dir, "_kernel_trace.csv"), "rb") as f, gzip.open(os.path.join(out, tag + "_kernel_trace.csv.gz"), "wb") as g:
         shutil.copyfileobj(f, g)
     fpath, wpath = find(fetch_dir, "_counter_collection.csv"), find(write_dir, "_counter_collection.csv")
-    for src, name in ((fpath, "pmc_fetch_size.csv.gz"), (wpath, "pmc_write_size.csv.gz")):
+    for src, name in ((fpath, tag + "_pmc_fetch_size.csv.gz"), (wpath, tag + "_pmc_write_size.csv.gz")):
         with open(src, "rb") as f, gzip.open(os.path.join(out, name), "wb") as g:
             shutil.copyfileobj(f, g)
     fe, wr = counter_avgs(fpath, "FETCH_SIZE"), counter_avgs(wpath, "WRITE_SIZE")
     summ = {
-        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu (two separate passes)",
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- <the profiled command> (two separate passes)",
         "unit": "KiB as reported; bytes = value*1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide "
                 "coalesced reads; other widths uncalibrated, so the doubled figure is an upper bound)",
     }
-    for k in ("k_chain_w", "k_level"):
-        if k in fe and k in wr:
-            summ[k + "_launches"] = fe[k][0]
-            summ[k + "_fetch_kib_avg"] = fe[k][1]
-            summ[k + "_write_kib_avg"] = wr[k][1]
-            summ[k + "_traffic_bytes_per_launch"] = (2.0 * fe[k][1] + wr[k][1]) * 1024.0
-    summ["sample_traffic_bytes_per_launch"] = summ.get("k_chain_w_traffic_bytes_per_launch")
-    json.dump(summ, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+    for k in sorted(set(fe) & set(wr)):
+        summ[k + "_launches"] = fe[k][0]
+        summ[k + "_fetch_kib_avg"] = fe[k][1]
+        summ[k + "_write_kib_avg"] = wr[k][1]
+        summ[k + "_traffic_bytes_per_launch"] = (2.0 * fe[k][1] + wr[k][1]) * 1024.0
+    summ["sample_traffic_bytes_per_launch"] = summ.get("k_level_sample_traffic_bytes_per_launch")
+    name = "pmc_summary.json" if tag == "bench_config2" else tag + "_pmc_summary.json"
+    json.dump(summ, open(os.path.join(out, name), "w"), indent=1)
     print(json.dumps(summ, indent=1))
 
 
