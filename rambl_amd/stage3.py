@@ -14,8 +14,8 @@ trip to the device.  What the reference takes from its libraries is kept as it i
 branch-length preservation and its collapse of single-child parents, scipy's `linkage` applied to the ROWS of the
 upper-triangular distance matrix (single linkage, flat clusters at 1 - SIM), numpy's cyclic `resize` of coverage masks,
 `%f` formatting, and the key order of a CPython 2.7 dict for the printed list.  Parity is unpinned (the reference
-needs Python 2 with ete2 and holds no fixture); tests compare this module with a literal restatement
-(oracle/seed_otus_oracle.py) on random trees.
+needs Python 2 with ete2 and holds no fixture); tests compare this module with a literal restatement kept with the
+test infrastructure, on random trees.
 """
 import csv
 import math
