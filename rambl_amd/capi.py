@@ -135,7 +135,10 @@ class NativeReads:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().sc_reads_free(self._h)
+            try:
+                lib().sc_reads_free(self._h)
+            except TypeError:          # interpreter shutdown: the module globals are gone, the process frees the memory
+                pass
             self._h = None
 
     def _texts(self, text, off):
@@ -177,7 +180,10 @@ class NativeAln:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().sc_aln_close(self._h)
+            try:
+                lib().sc_aln_close(self._h)
+            except TypeError:          # interpreter shutdown
+                pass
             self._h = C.c_void_p()
 
     def __del__(self):

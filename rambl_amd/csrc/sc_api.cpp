@@ -156,7 +156,7 @@ struct LevelRequest { Worker* w; LevelItem item; int kind; bool timed; };
 // Launch streams are shared by all regions in flight.  A stream carries one batch at a time (`busy` = regions of that
 // batch whose stamp has not been seen yet), so kernels of different regions never queue behind each other: a level
 // that finds every stream busy waits in `pending` and leaves with the next batch of its kind.
-struct LaunchStream { hipStream_t st = nullptr; int busy = 0; };
+struct LaunchStream { hipStream_t st = nullptr; int busy = 0; int unretired = 0; };
 struct Ctx {
     int device = 0;
     std::string last_error;
@@ -214,7 +214,9 @@ struct Worker {
     std::string level_err;
     double t_batch_launched = 0;      // diagnostics: when the level's batch was launched, and its size
     int batch_n = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;     // ev0 / ev1: the pair of the level being launched (from ev_pool when timing)
+    std::vector<hipEvent_t> ev_pool;  // want_timing: one pair per sampler level of the region, read when the region is done
+    size_t ev_used = 0;
     LevelParams* Ph = nullptr;        // host-mapped: written here, read by the level's kernel over PCIe
     LevelParams* Pm = nullptr;        //   its device address
     LevelParams* Pd = nullptr;        // device copy, only for the grid kernels of very large levels
@@ -240,8 +242,6 @@ struct Worker {
 void Worker::init() {
     HIPCHK(hipSetDevice(ctx->device));
     if (!st) { HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
-    HIPCHK(hipEventCreate(&ev0));
-    HIPCHK(hipEventCreate(&ev1));
     HIPCHK(hipEventCreateWithFlags(&ev_sync, hipEventBlockingSync | hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&Ph, sizeof(LevelParams), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&Pm, Ph, 0));
@@ -314,11 +314,18 @@ void Ctx::serve_levels() {
             launch_level_batch(st, kind, batch, n);
             if (timed) for (int i = 0; i < n; i++) (void)hipEventRecord(who[i]->ev1, st);
             lstreams[(size_t)fs].busy = n;
+            lstreams[(size_t)fs].unretired++;
             const double tl = now_ms();
             for (int i = 0; i < n; i++) { who[i]->cur_stream = fs; who[i]->t_batch_launched = tl; who[i]->batch_n = n; flying.push_back(who[i]); }
             progressed = true;
         }
         if (progressed) { idle_spins = 0; continue; }
+        if ((idle_spins & 0xFFu) == 0) {
+            // idle: let the runtime retire finished launches of one free stream (it does so only when asked; left alone
+            // they pile up for whoever synchronises the device next, ~10 us each)
+            for (auto& ls : lstreams)
+                if (ls.busy == 0 && ls.unretired > 0) { if (hipStreamQuery(ls.st) == hipSuccess) ls.unretired = 0; break; }
+        }
         __builtin_ia32_pause();
         if ((++idle_spins & 0xFFFFFu) == 0) {
             // nothing has moved for a while: has a stream died under its batch?
@@ -469,7 +476,9 @@ void Worker::thread_device(const std::string& G, const std::vector<AlignedRead>&
     HIPCHK(hipMemcpyAsync(T.off.data(), d.off, sizeof(int) * ((size_t)ncls + 1), hipMemcpyDeviceToHost, st));
     if (m_bases > 0) HIPCHK(hipMemcpyAsync(T.pool.data(), pool_sorted, sizeof(int) * (size_t)m_bases, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&err, d.err, sizeof(int), hipMemcpyDeviceToHost, st));
+    const double t_sync0 = now_ms();
     HIPCHK(hipStreamSynchronize(st));
+    if (getenv("SC_SYNC_LOG")) fprintf(stderr, "sync thread_device %.3f ms\n", now_ms() - t_sync0);
     if (err) throw ScError(SC_ERR_ARG, "a read runs outside the window or past its own bases");
     const int INF = 0x7fffffff;
     auto fix = [&](std::vector<int>& v) { for (int& x : v) if (x == 0x7f7f7f7f) x = INF; };
@@ -519,6 +528,8 @@ static void fmt_g17(std::string& out, double v) {
 
 void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     const int n_reads = (int)job.reads.size();
+    const double t_cluster0 = now_ms();
+    ev_used = 0;
     const sc_params& pa = job.params;
     const ld e = (ld)pa.error_rate, tau = (ld)pa.tau, diff = (ld)pa.diff_rate;     // float widened, StrainCall.cpp:58-154
     const int K = f.K;
@@ -601,7 +612,9 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                             f.pools_sorted ? 1 : 0, d_sup);
         if (!esrc.empty())
             HIPCHK(hipMemcpyAsync(f.out_support.data(), d_sup, sizeof(int) * esrc.size(), hipMemcpyDeviceToHost, st));
+        const double t_sync0 = now_ms();
         HIPCHK(hipStreamSynchronize(st));
+        if (getenv("SC_SYNC_LOG")) fprintf(stderr, "sync uploads+edge_support %.3f ms (since cluster start %.3f)\n", now_ms() - t_sync0, now_ms() - t_cluster0);
         job.edge_support = f.out_support;
     }
 
@@ -726,6 +739,16 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         }
         H.seq = ++seq;
         level_want = H.seq;
+        if (timed) {
+            // a fresh pair of events per sampler launch; their times are read after the walk, not between levels
+            if (ev_used + 2 > ev_pool.size()) {
+                hipEvent_t a = nullptr, b = nullptr;
+                HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+                ev_pool.push_back(a); ev_pool.push_back(b);
+            }
+            ev0 = ev_pool[ev_used]; ev1 = ev_pool[ev_used + 1];
+            ev_used += 2;
+        }
         const double t_launched = level_log ? now_ms() : 0.0;
         if (ctx->workers.size() == 1) {
             // a single region in flight: nobody to batch with, so the worker launches its level itself and watches the stamp
@@ -736,6 +759,9 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             launch_level_batch(ls, level_kind(H), batch, 1);
             if (timed) HIPCHK(hipEventRecord(ev1, ls));
             t_batch_launched = level_log ? now_ms() : 0.0; batch_n = 1;
+            // while this level runs: let the runtime retire the launches behind it (it does so only when asked, and a
+            // region leaves ~1 500 of them for whoever synchronises the device next: ~10 us each)
+            (void)hipStreamQuery(ls);
             unsigned spins = 0;
             while (__atomic_load_n(&Rh->seq, __ATOMIC_ACQUIRE) != H.seq) {
                 __builtin_ia32_pause();
@@ -749,7 +775,6 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             ctx->submit_level(LevelRequest{this, LevelItem{jd, H, Pm, Rd}, level_kind(H), timed});
             wait_level();
         }
-        if (timed) HIPCHK(hipEventSynchronize(ev1));
         level_launches++;
         if (chain) {
             sampler_launches++; sampler_copies += Q;
@@ -769,11 +794,6 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             t_last_done = t_done;
         }
         job.stats.xcd_levels[Rh->xcc & 7]++;
-        if (timed) {
-            float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
-            sampler_ms += ms;
-        }
     };
 
     for (int level = 0; level < f.n_levels; level++) {
@@ -1007,6 +1027,13 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         }
     }
     if (level_log) fclose(level_log);
+    for (size_t k = 0; k + 1 < ev_used; k += 2) {
+        float ms = 0;
+        HIPCHK(hipEventSynchronize(ev_pool[k + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, ev_pool[k], ev_pool[k + 1]));
+        sampler_ms += ms;
+    }
+    ev_used = 0;
     job.stats.sampler_kernel_ms = sampler_ms;
     job.stats.sampler_launches = sampler_launches;
     job.stats.sampler_read_copies = sampler_copies;
@@ -1163,8 +1190,7 @@ void sc_ctx_destroy(sc_ctx* h) {
         if (w->Ph) (void)hipHostFree(w->Ph);
         if (w->Pd) (void)hipFree(w->Pd);
         if (w->Rh) (void)hipHostFree(w->Rh);
-        if (w->ev0) (void)hipEventDestroy(w->ev0);
-        if (w->ev1) (void)hipEventDestroy(w->ev1);
+        for (hipEvent_t e : w->ev_pool) (void)hipEventDestroy(e);
         if (w->ev_sync) (void)hipEventDestroy(w->ev_sync);
         if (w->st && w->own_stream) (void)hipStreamDestroy(w->st);
     }
@@ -1345,7 +1371,7 @@ int sc_msa_align(sc_ctx* h, const char* seq_text, const int* seq_off, int n, cha
         if (!rows_out || (long)n * (ncol + 1) > cap) rc = SC_ERR_CAPACITY;
         else for (int i = 0; i < n; i++) { std::memcpy(rows_out + (long)i * (ncol + 1), rows[i].data(), (size_t)ncol); rows_out[(long)i * (ncol + 1) + ncol] = 0; }
         (void)hipHostFree(w.Ph); (void)hipFree(w.Pd); (void)hipHostFree(w.Rh);
-        (void)hipEventDestroy(w.ev0); (void)hipEventDestroy(w.ev1); (void)hipEventDestroy(w.ev_sync); (void)hipStreamDestroy(w.st);
+        (void)hipEventDestroy(w.ev_sync); (void)hipStreamDestroy(w.st);
         return rc;
     } catch (const ScError& ex) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->last_error = ex.what(); return ex.code; }
     catch (const std::exception& ex) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->last_error = ex.what(); return SC_ERR_HIP; }
