@@ -163,6 +163,10 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
 
+    # the library's launch and setup streams want a hardware queue each; HIP reads this once, when it initialises
+    # (rambl_amd/__init__.py sets it too, but torch touches the device first here)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -279,7 +279,7 @@ def main(argv=None):
     ap.add_argument("alignments", help="BAM or SAM text of the reads aligned to the seed genes")
     ap.add_argument("-o", "--out-dir", default=".")
     ap.add_argument("-p", "--prefix", default="rambl")
-    ap.add_argument("-s", "--streams", type=int, default=32, help="regions in flight per GPU")
+    ap.add_argument("-s", "--streams", type=int, default=128, help="regions in flight per GPU")
     ap.add_argument("-j", "--ingest-workers", type=int, default=4, help="host threads reading the alignments")
     for k, v in RAMBL_DEFAULTS.items():
         ap.add_argument("--" + k.replace("_", "-"), default=v, type=type(v))
