@@ -1,14 +1,17 @@
 // Host driver + C-ABI of libstraincall_hip.so.  See include/straincall_hip.h.
 //
-// Per region: build the partial order graph (sc_graph.cpp; the insertion MSA runs
-// on the device through k_msa), flatten it level-major, upload it once, compute
-// every edge support on the device (k_edge_support), then walk the levels of
-// /root/reference/StrainCall/NonparametricClustering.cpp:262-582.  The walk keeps
-// only the scalar bookkeeping of the candidate strains on the host (6x6 models,
-// abundances, pruning / extension decisions); the per-read work of every level --
-// log-likelihood update, soft update, Polya-urn sampler -- is one k_level launch
-// on the region's stream, and the per-strain read log-likelihood rows never leave
-// HBM.
+// Per region (a worker thread): build the partial order graph (sc_graph.cpp; the per-base threading of the reads and
+// the insertion MSA run on the device: k_thread_*, k_msa), flatten it level-major, upload it once, compute every edge
+// support on the device (k_edge_support), then walk the levels of
+// /root/reference/StrainCall/NonparametricClustering.cpp:262-582.  The walk keeps only the scalar bookkeeping of the
+// candidate strains on the host, in long double as the reference has it (substitution models, abundances, pruning /
+// extension decisions); the per-read work of a level -- rows of new candidates, log-likelihood update, soft update or
+// Polya-urn sampler -- is ONE kernel launch (k_level / k_level_sample), its parameters read from host-mapped memory,
+// its results and a completion stamp written back to it; the per-strain read log-likelihood rows never leave HBM.
+//
+// Per context: the level server (Ctx::serve_levels), the one thread that launches level kernels and watches the stamps.
+// Levels of different regions that need the same kernel leave as one grid on one of a few shared launch streams, so
+// that a hundred regions in flight need no more hardware queues than the GPU runs side by side.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -214,7 +217,7 @@ struct Worker {
     std::string level_err;
     double t_batch_launched = 0;      // diagnostics: when the level's batch was launched, and its size
     int batch_n = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sync = nullptr;     // ev0 / ev1: the pair of the level being launched (from ev_pool when timing)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;     // the pair of the level being launched (from ev_pool when timing)
     std::vector<hipEvent_t> ev_pool;  // want_timing: one pair per sampler level of the region, read when the region is done
     size_t ev_used = 0;
     LevelParams* Ph = nullptr;        // host-mapped: written here, read by the level's kernel over PCIe
@@ -242,7 +245,6 @@ struct Worker {
 void Worker::init() {
     HIPCHK(hipSetDevice(ctx->device));
     if (!st) { HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
-    HIPCHK(hipEventCreateWithFlags(&ev_sync, hipEventBlockingSync | hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&Ph, sizeof(LevelParams), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&Pm, Ph, 0));
     HIPCHK(hipMalloc((void**)&Pd, sizeof(LevelParams)));
@@ -1191,7 +1193,6 @@ void sc_ctx_destroy(sc_ctx* h) {
         if (w->Pd) (void)hipFree(w->Pd);
         if (w->Rh) (void)hipHostFree(w->Rh);
         for (hipEvent_t e : w->ev_pool) (void)hipEventDestroy(e);
-        if (w->ev_sync) (void)hipEventDestroy(w->ev_sync);
         if (w->st && w->own_stream) (void)hipStreamDestroy(w->st);
     }
     ctx->workers.clear();
@@ -1371,7 +1372,7 @@ int sc_msa_align(sc_ctx* h, const char* seq_text, const int* seq_off, int n, cha
         if (!rows_out || (long)n * (ncol + 1) > cap) rc = SC_ERR_CAPACITY;
         else for (int i = 0; i < n; i++) { std::memcpy(rows_out + (long)i * (ncol + 1), rows[i].data(), (size_t)ncol); rows_out[(long)i * (ncol + 1) + ncol] = 0; }
         (void)hipHostFree(w.Ph); (void)hipFree(w.Pd); (void)hipHostFree(w.Rh);
-        (void)hipEventDestroy(w.ev_sync); (void)hipStreamDestroy(w.st);
+        (void)hipStreamDestroy(w.st);
         return rc;
     } catch (const ScError& ex) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->last_error = ex.what(); return ex.code; }
     catch (const std::exception& ex) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->last_error = ex.what(); return SC_ERR_HIP; }

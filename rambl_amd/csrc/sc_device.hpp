@@ -1,4 +1,4 @@
-// Device-side data layout shared by the host driver (sc_cluster.cpp) and the
+// Device-side data layout shared by the host driver (sc_api.cpp) and the
 // HIP kernels (sc_kernels.hip).  All pointers are device pointers unless the
 // field name ends in _h (host-mapped pinned memory written/read by kernels).
 #pragma once

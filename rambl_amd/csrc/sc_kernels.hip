@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(256) void k_thread_sort(const int* __restrict__ off
 }
 
 // --------------------------------------------------------------------------
-// host-callable launchers (called from sc_cluster.cpp / sc_api.cpp)
+// host-callable launchers (called from sc_api.cpp)
 void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node, const int* pool_ptr, const int* pool_rid,
                          const int* pool_cn, const uint8_t* node_is_end, const int* edge_src, int n_edges, int sorted,
                          int* support) {

@@ -102,73 +102,74 @@ def read_align_end_pos(p0, cigars):
     return p0 - 1
 
 
-def crop_read_within_window(wp0, wp1, seq, qual, cigars, rp0, rp1):
-    """StrainCall.cpp:291-414 -> (crop_seq, crop_cigar).  Raises where the C++
-    would throw (std::string::substr past the end)."""
-    i = j = ki = kj = 0
-    crop = []
-    it = 0
-    op, opl = cigars[it]
-    if op == "S":
-        i += opl
-        it += 1
-    op, opl = cigars[it]
-    if rp0 < wp0 and rp0 < wp1:
-        while rp0 < wp0 and rp0 < wp1:
-            ki = 0
-            op, opl = cigars[it]
-            if op == "M":
-                while ki < opl:
-                    if rp0 == wp0:
-                        break
-                    ki += 1; i += 1; rp0 += 1
-            elif op == "D":
-                while ki < opl:
-                    if rp0 == wp0:
-                        break
-                    ki += 1; rp0 += 1
-            elif op == "I":
-                i += opl
-            it += 1
-    else:
-        it += 1
-    if ki < opl:
-        crop.append([op, opl - ki])
-    crop.extend([list(c) for c in cigars[it:]])
+def crop_read_within_window(w0, w1, seq, qual, ops, r0, r1):
+    """The read inside the window [w0, w1] (StrainCall.cpp:291-414) -> (bases, CIGAR text).
 
-    rit = len(cigars) - 1
-    op, opl = cigars[rit]
-    if op == "S":
-        j += opl
-        rit -= 1
-        crop.pop()
-    op, opl = cigars[rit]
-    while rp1 > wp1 and rp1 > wp0:
-        kj = 0
-        op, opl = cigars[rit]
-        if op == "M":
-            while kj < opl:
-                if rp1 == wp1:
-                    break
-                kj += 1; j += 1; rp1 -= 1
-        elif op == "D":
-            while kj < opl:
-                if rp1 == wp1:
-                    break
-                kj += 1; rp1 -= 1
+    Soft clips go; the front of a read that starts before the window and the back of one that ends after it are cut
+    away along a reference coordinate map of the operations: M and D are clipped position by position, an insertion
+    in front of the first / behind the last kept reference position leaves with its bases, operations the reference
+    does not know to consume anything (N, H, P) stay as they are.  Same rules as `crop_to_window` in
+    rambl_amd/csrc/sc_ingest.cpp (the product's reader); raises where the C++ of the reference would run past a vector
+    or a string."""
+    n = len(ops)
+    lead = trail = 0
+    first = 0
+    if ops[0][0] == "S":
+        lead, first = ops[0][1], 1
+    if first >= n:
+        raise IndexError("crop: nothing but a soft clip")
+    kept = []
+    k = first
+    if r0 < w0 and r0 < w1:
+        # walk the reference cursor up to the window start
+        cur, last_op, used_last = r0, None, 0
+        while cur < w0 and cur < w1:
+            op, ln = ops[k]                      # IndexError: the read never reaches the window
+            k += 1
+            used = 0
+            if op in "MD":
+                used = max(0, min(ln, w0 - cur))
+                cur += used
+                if op == "M":
+                    lead += used
+            elif op == "I":
+                lead += ln
+            last_op, used_last = (op, ln), used
+        if used_last < last_op[1]:
+            kept.append([last_op[0], last_op[1] - used_last])        # the operation the window starts in
+    else:
+        if ops[k][1] > 0:
+            kept.append(list(ops[k]))
+        k += 1
+    kept.extend(list(o) for o in ops[k:])
+    # the same from the other end, on the operations still held
+    last = n - 1
+    if ops[last][0] == "S":
+        trail = ops[last][1]
+        last -= 1
+        kept.pop()
+    cur = r1
+    while cur > w1 and cur > w0:
+        if last < 0:
+            raise IndexError("crop: the read never comes back into the window")
+        op, ln = ops[last]
+        last -= 1
+        used = 0
+        if op in "MD":
+            used = max(0, min(ln, cur - w1))
+            cur -= used
+            if op == "M":
+                trail += used
         elif op == "I":
-            j += opl
-        rit -= 1
-        if kj == opl or op == "I":
-            crop.pop()
+            trail += ln
+        if used == ln or op == "I":
+            kept.pop()
         else:
-            crop[-1][1] -= kj
-    if i > len(seq) or j > len(qual):
+            kept[-1][1] -= used
+    if lead > len(seq) or trail > len(qual):
         raise ValueError("crop_read_within_window: substr out of range")
-    cnt = len(seq) - i - j
-    crop_seq = seq[i:] if cnt < 0 else seq[i:i + cnt]
-    crop_cigar = "".join("%d%s" % (ln, o) for o, ln in crop)
-    return crop_seq, crop_cigar
+    cnt = len(seq) - lead - trail
+    return (seq[lead:] if cnt < 0 else seq[lead:lead + cnt]), "".join("%d%s" % (ln, o) for o, ln in kept)
 
 
 def max_insert_size(cigar):
