@@ -82,6 +82,47 @@ def cpu_baseline(data_dir, fasta, sam, roi):
                 fasta=fasta_text), args
 
 
+def depth_scan_leg(device, bases=100_000_000, depth=20.0, reps=3):
+    """The HBM-bound kernel of the repository, beside the headline (whose sampler is latency-bound by construction): rambl.py
+    stage 1 (coverage_all_samples.py) on a synthetic 10^8-base input -- k_depth_segments streams 4 algorithmic bytes per
+    cell of the difference array; its duration comes from HIP events inside sc_depth_scan_runs."""
+    import ctypes as C
+    import numpy as np
+    from rambl_amd import capi, stage1
+    lib = capi.lib()
+    rng = np.random.default_rng(3)
+    n_refs = bases // 1500
+    ref_len = rng.integers(1400, 1601, n_refs).astype(np.int32)
+    n_runs = int(ref_len.sum() * depth / 150)
+    run_ref = np.sort(rng.integers(0, n_refs, n_runs)).astype(np.int32)
+    start = np.maximum((rng.random(n_runs) * (ref_len[run_ref] - 150)).astype(np.int64) + 1, 1).astype(np.int32)
+    end = np.minimum(start + 149, ref_len[run_ref]).astype(np.int32)
+    ip = C.POINTER(C.c_int)
+    cap = 4 * n_refs
+    iv = [np.zeros(cap, dtype=np.int32) for _ in range(3)]
+    sm, cn = np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int32)
+    lib.sc_depth_scan_runs.argtypes = [C.c_int, ip, C.c_int, ip, ip, ip, C.c_long, C.c_int, ip, ip, ip, C.POINTER(C.c_long), ip, C.c_int, ip,
+                                       C.POINTER(stage1.DepthStats)]
+    best = None
+    for _ in range(reps):
+        n, st = C.c_int(), stage1.DepthStats()
+        rc = lib.sc_depth_scan_runs(device, ref_len.ctypes.data_as(ip), n_refs, run_ref.ctypes.data_as(ip), start.ctypes.data_as(ip),
+                                    end.ctypes.data_as(ip), n_runs, 10, iv[0].ctypes.data_as(ip), iv[1].ctypes.data_as(ip),
+                                    iv[2].ctypes.data_as(ip), sm.ctypes.data_as(C.POINTER(C.c_long)), cn.ctypes.data_as(ip), cap, C.byref(n),
+                                    C.byref(st))
+        if rc != 0:
+            return {"error": rc}
+        if best is None or st.segments_ms < best[0]:
+            best = (st.segments_ms, st.mark_ms, st.cells, st.runs, n.value)
+    ok = int(sm[:best[4]].sum()) == int((end - start + 1).sum())
+    gbs = 4.0 * best[2] / (best[0] * 1e-3) / 1e9
+    return {"kernel": "k_depth_segments<4> (rambl.py stage 1: per-base depth over all references -> merged intervals with mean depth)",
+            "workload": "%d reference bases in %d genes, %d aligned runs of 150 bases" % (int(ref_len.sum()), n_refs, n_runs),
+            "bound": "hbm", "algorithmic_bytes": 4 * best[2], "launch_ms": best[0], "achieved": gbs, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": gbs * 1e9 / HBM_PEAK, "mark_kernel_ms": best[1], "intervals": best[4], "depth_sums_add_up": ok,
+            "traffic_source": "profiles/r02/depth_1e8_pmc_summary.json: FETCH 2 x 195 MiB + WRITE 3.6 MB per launch"}
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` outside a launcher: start the N ranks (before this process touches any GPU) and
     relay rank 0's line."""
@@ -157,6 +198,7 @@ def main():
     ap.add_argument("--sample-roi", default="700-860")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-set", action="store_true", help="N = 1: skip the 100-region leg (regions_in_flight)")
+    ap.add_argument("--no-depth", action="store_true", help="N = 1: skip the stage-1 depth-scan leg (hbm_bound_kernel)")
     ap.add_argument("--streams", type=int, default=128, help="regions in flight per GPU on the 100-region set")
     a = ap.parse_args()
 
@@ -342,6 +384,8 @@ def main():
                                      "ingest_seconds": ingest_s, "value_with_ingest": n_total / (dts + ingest_s),
                                      "read_copies_after_ingest": n_graph_set, "contigs": "".join(texts).count(">"),
                                      "avg_sampler_level_ms": sum(s["chain_wall_ticks"] for s in st_set) / 1e5 / max(sum(s["sampler_launches"] for s in st_set), 1)}
+    if not a.no_depth:
+        line["hbm_bound_kernel"] = depth_scan_leg(local)
     print(json.dumps(line), flush=True)
 
 
