@@ -228,7 +228,7 @@ struct Worker {
     unsigned seq = 0;                 // stamp of the last level launched
     DevBuf b_ent_rid, b_ent_cn, b_ent_lab_off, b_ent_lab_len, b_ent_first, b_ent_qoff, b_labels, b_mate_ptr, b_mate_idx,
         b_ll, b_has, b_isnew, b_tabA, b_tabLf, b_qcode, b_qent, b_quid, b_out_ptr, b_out_node, b_pool_ptr, b_pool_rid,
-        b_pool_cn, b_isend, b_esrc, b_support;
+        b_pool_cn, b_isend, b_esrc, b_support, b_jobdev;
     DevBuf m_seqs, m_off, m_cols0, m_cols1, m_counts, m_moves, m_trace, m_out, m_edge;
     DevBuf t_ref, t_pos, t_seqoff, t_seq, t_cigoff, t_cigop, t_ciglen, t_lut, t_tabs, t_pool, t_pool2;
 
@@ -597,6 +597,9 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     jd.qcode = (uint8_t*)b_qcode.ensure((size_t)qcap + 8);
     jd.qent = (int*)b_qent.ensure(sizeof(int) * (size_t)qcap);
     jd.quid = (int*)b_quid.ensure(sizeof(int) * (size_t)qcap);
+    // the batched level kernels find the region through a pointer: the block travels once, with the uploads
+    const JobDev* jd_dev = (const JobDev*)b_jobdev.ensure(sizeof(JobDev));
+    HIPCHK(hipMemcpyAsync((void*)jd_dev, &jd, sizeof jd, hipMemcpyHostToDevice, st));
 
     // ---- a16: every edge support on the device
     {
@@ -755,7 +758,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         if (ctx->workers.size() == 1) {
             // a single region in flight: nobody to batch with, so the worker launches its level itself and watches the stamp
             LevelBatch batch;
-            batch.it[0] = LevelItem{jd, H, Pm, Rd};
+            batch.it[0] = LevelItem{jd_dev, H, Pm, Rd};
             hipStream_t ls = ctx->lstreams[0].st;
             if (timed) HIPCHK(hipEventRecord(ev0, ls));
             launch_level_batch(ls, level_kind(H), batch, 1);
@@ -774,7 +777,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 }
             }
         } else {
-            ctx->submit_level(LevelRequest{this, LevelItem{jd, H, Pm, Rd}, level_kind(H), timed});
+            ctx->submit_level(LevelRequest{this, LevelItem{jd_dev, H, Pm, Rd}, level_kind(H), timed});
             wait_level();
         }
         level_launches++;

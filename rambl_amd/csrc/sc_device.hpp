@@ -76,20 +76,21 @@ struct LevelParams {
     double lpt[MAXS * KK];       // log sub(a,b) - log comp(a): compact [S][K][K], K = JobDev::K
 };
 
-// One launch serves the current level of up to MAXB regions: workgroup b takes batch.it[b].  Everything the
-// level needs to find its region travels in the kernel-argument segment (scalar loads the compiler can repeat
-// instead of holding registers): the region's arrays, the level's scalars, the host-mapped parameter / result
-// blocks.  MAXB keeps the segment below 4 KB.
+// One launch serves the current level of up to MAXB regions: workgroup b takes batch.it[b].  What the level needs
+// to find its region travels in the kernel-argument segment: a pointer to the region's JobDev (device memory, filled
+// once per region, read through the constant address space), the level's scalars, the host-mapped parameter /
+// result blocks.  MAXB keeps the segment below 4 KB.
 struct LevelParams;
 struct LevelResult;
 struct LevelItem {
-    JobDev job;
+    const JobDev* job;           // device memory; constant while the region is walked
     LevelHdr h;
     const LevelParams* P;        // host-mapped
     LevelResult* R;              // host-mapped
 };
-constexpr int MAXB = 14;
+constexpr int MAXB = 48;
 struct LevelBatch { LevelItem it[MAXB]; };
+static_assert(sizeof(LevelBatch) <= 4096, "kernel-argument segment");
 
 // Per-level results, written by the kernel into host-mapped pinned memory; `seq` last (system-scope release).
 struct LevelResult {

@@ -271,8 +271,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 constexpr int UWIN = 1024;     // uniforms staged in LDS (fp32), refilled in halves
 
-template <int NQ, bool ROWS_LDS, int NW>
-__device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelHdr& h, const StrainParam* s_sp, LevelResult* __restrict__ R,
+template <int NQ, bool ROWS_LDS, int NW, class JD>
+__device__ __forceinline__ void urn_chain_q(const JD& job, const LevelHdr& h, const StrainParam* s_sp, LevelResult* __restrict__ R,
                                             const int* s_slot, volatile double* s_a, volatile double* s_p, unsigned* s_kf,
                                             const float* s_a0f, unsigned* s_cnt, int* s_x, float* s_uwin, const float* rows_lds, int stride, int tid) {
     constexpr int SPL = 4 * NQ, SP = 16 * NQ;               // strains per lane, capacity
@@ -464,6 +464,10 @@ __device__ __forceinline__ void urn_chain_q(const JobDev& job, const LevelHdr& h
 // of (strain, read) items the host runs the first two on a grid instead (k_level_copy, k_level_update) and
 // says so in LevelHdr::done.
 enum { LV_COPIES_DONE = 1, LV_ITEMS_DONE = 2 };
+// The region's arrays as the batched level kernels see them: a block of device memory that does not change while the
+// region is walked, read through the constant address space -- scalar loads the compiler may repeat at will, exactly
+// like kernel arguments (which hold only a pointer to it: LevelItem).
+typedef const __attribute__((address_space(4))) JobDev KJob;
 
 // grid, phase 0: rows of strains created by the last extension (Strain copy, Strain.cpp:73-83); copies are
 // independent (a destination row is a free row, a source row a surviving parent's).  P: device copy.
@@ -524,7 +528,8 @@ __device__ __forceinline__ void stage_params(const LevelHdr& h, const LevelParam
 }
 
 // phase 0 inside the workgroup
-__device__ __forceinline__ void phase_copies(const JobDev& job, const LevelHdr& h, const int* s_copy, int tid, int nt) {
+template <class JD>
+__device__ __forceinline__ void phase_copies(const JD& job, const LevelHdr& h, const int* s_copy, int tid, int nt) {
     const long stride = job.ll_stride;
     for (int c = 0; c < ((h.done & LV_COPIES_DONE) ? 0 : h.n_copy); c++) {
         const double2* src = reinterpret_cast<const double2*>(job.ll + (long)s_copy[c] * stride);
@@ -543,7 +548,8 @@ __device__ __forceinline__ void phase_copies(const JobDev& job, const LevelHdr& 
 
 // phase 1: read log-likelihood update, NonparametricClustering.cpp:343-391, then the reads of the level are
 // present in read_loglik (`has`).  s_lpt: the strains' log tables in LDS.
-__device__ __forceinline__ void phase_update(const JobDev& job, const LevelHdr& h, const StrainParam* s_sp, const int* s_lab,
+template <class JD>
+__device__ __forceinline__ void phase_update(const JD& job, const LevelHdr& h, const StrainParam* s_sp, const int* s_lab,
                                              const double* s_lpt, int tid, int nt) {
     const int S = h.S, K = job.K, K2 = K * K, e0 = h.e0, Rn = h.e1 - h.e0;
     const long stride = job.ll_stride;
@@ -639,7 +645,8 @@ __device__ __forceinline__ void phase_update(const JobDev& job, const LevelHdr& 
 }
 
 // phase 2: draw slots q = (entry, copy); the reference walks copies from cn down to 1 (:161-167)
-__device__ __forceinline__ void phase_slots(const JobDev& job, const LevelHdr& h, int tid, int nt) {
+template <class JD>
+__device__ __forceinline__ void phase_slots(const JD& job, const LevelHdr& h, int tid, int nt) {
     const int e0 = h.e0, Rn = h.e1 - h.e0;
     for (int r = tid; r < Rn; r += nt) {
         const int e = e0 + r;
@@ -732,7 +739,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(LevelBatch batch
     const unsigned long long wall0 = wall_clock64();
     const LevelItem& it = batch.it[blockIdx.x];
     const LevelHdr& h = it.h;
-    const JobDev& job = it.job;
+    KJob& job = *(KJob*)it.job;
     const LevelParams* __restrict__ P = it.P;
     LevelResult* __restrict__ R = it.R;
     const LevelLds l = level_lds(s_raw);
@@ -838,7 +845,7 @@ __global__ __launch_bounds__(512) void k_level(LevelBatch batch) {
     const unsigned long long wall0 = wall_clock64();
     const LevelItem& it = batch.it[blockIdx.x];
     const LevelHdr& h = it.h;
-    const JobDev& job = it.job;
+    KJob& job = *(KJob*)it.job;
     const LevelParams* __restrict__ P = it.P;
     LevelResult* __restrict__ R = it.R;
     const LevelLds l = level_lds(s_raw);

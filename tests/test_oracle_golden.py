@@ -38,6 +38,18 @@ def test_oracle_matches_reference(name, tmp_path, oracle_bin):
     assert tr == exp_tr            # long double, 17 significant digits: identical text
 
 
+@pytest.mark.parametrize("name", sorted(INDEX)[:6])
+def test_oracle_counting_edge_support_is_the_same(name, tmp_path, oracle_bin, monkeypatch):
+    """SC_ORACLE_FAST_SUPPORT=1 (edge support by counting instead of the reference's double loop over two read pools,
+    oracle/o_graph.h) must not change a byte: it exists only so that the oracle can finish the unthinned configs[3]
+    case (tests/golden/config4_full_D100000), where the double loop and the reference itself cannot."""
+    args, exp_fa, exp_g, exp_tr = load_case(name, str(tmp_path))
+    monkeypatch.setenv("SC_ORACLE_FAST_SUPPORT", "1")
+    fa, tr = T.run_oracle(args, str(tmp_path), trace=True)
+    g, _ = T.run_oracle(args, str(tmp_path), graph=True)
+    assert fa == exp_fa and g == exp_g and tr == exp_tr
+
+
 def test_oracle_msa_vectors(oracle_bin):
     cases = json.loads(gzip.open(os.path.join(GOLD, "msa_vectors.json.gz")).read())
     assert len(cases) >= 100
