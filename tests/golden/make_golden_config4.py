@@ -12,6 +12,13 @@ called per candidate, out-edge and level; at depth 100 000 that is ~1e10 compari
 total, which the reference cannot finish (days).  -D 3000 is the largest depth it finishes in about an hour.
 
 Only the inputs' digests, the argv and the reference's stdout are stored.
+
+  config4_full_D100000 is NOT made by this script and not by the reference: it is the stdout of the oracle
+  (oracle/straincall_oracle) with SC_ORACLE_FAST_SUPPORT=1 -- the same edge support computed by counting, checked
+  byte-equal to the literal double loop on the committed cases (tests/test_oracle_golden.py) -- on the same
+  inputs with -D 100000 (35 minutes, 7 GB):
+      cd <workdir>; SC_ORACLE_FAST_SUPPORT=1 PATH=oracle/tools:$PATH TMPDIR=. oracle/straincall_oracle \
+          -r deep4m:1-1500 -q 0 -D 100000 -I 13 -l 70 -t 0.02 -d 0.02 -w 5000 seed_otus.fasta reads.sam
 usage: python tests/golden/make_golden_config4.py D [D ...]     (runs the given depths concurrently)
 """
 import hashlib

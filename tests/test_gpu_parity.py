@@ -447,6 +447,20 @@ def test_config4_million_reads_match_reference(depth, million_reads):
     assert got == open(os.path.join(gold, "expected.fa")).read()
 
 
+def test_config4_million_reads_unthinned_matches_oracle(million_reads):
+    """configs[3] with no thinning at all (-D 100000): every one of the 10^6 reads reaches the graph (~590 000 distinct
+    reads, ~100 000 read copies per level: the closed-form levels, grid updates, 600 MB of pools).  The reference cannot
+    finish this case (quadratic edge support); the expected FASTA is the ORACLE's, run with its counting edge support
+    (tests/golden/config4_full_D100000/meta.json says how)."""
+    import json
+    fa, sam = million_reads
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config4_full_D100000")
+    meta = json.load(open(os.path.join(gold, "meta.json")))
+    assert _sha(fa) == meta["fasta_sha256"] and _sha(sam) == meta["sam_sha256"]
+    got = T.run_product(meta["argv"] + [fa, sam])
+    assert got == open(os.path.join(gold, "expected.fa")).read()
+
+
 @pytest.mark.parametrize("seed", [2, 6])
 def test_region_from_bam_matches_oracle(seed, tmp_path, oracle_bin, monkeypatch):
     """BAM in (read by the library's own BGZF / BAM decoder: no samtools in the image), FASTA out: equal to the oracle
