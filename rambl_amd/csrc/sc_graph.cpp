@@ -260,7 +260,8 @@ void PoGraph::add_dash_chain(int a, int b, int l, const std::vector<std::pair<in
         int w = new_node(ST_INS, "-");
         auto& pool = nodes[w].pool;
         pool.reserve(crp.size());
-        for (const auto& rc : crp) pool.push_back({rc.first, rc.second, "-"});
+        const int dash = intern("-");
+        for (const auto& rc : crp) pool.push_back({rc.first, rc.second, dash});
         gap.push_back(w);
     }
     add_edge_gap_to(a, b, gap);
@@ -327,7 +328,7 @@ void PoGraph::canonize_insert_at_level(int i) {
             for (char ch : rows[t]) {
                 std::string lab(1, ch);
                 int w = new_node(ST_INS, lab);
-                nodes[w].pool.push_back({rid, rcn, lab});
+                nodes[w].pool.push_back({rid, rcn, intern(lab)});
                 ng.push_back(w);
             }
             add_edge_gap_to(inserts[t].u, inserts[t].v, ng);
@@ -338,7 +339,29 @@ void PoGraph::canonize_insert_at_level(int i) {
 }
 
 // cpp:571-622
+// The level at which the walk below first takes w off its list is w's distance from the root over the edges the walk
+// follows (out-edges to nodes that are no deletions, and the siblings of those nodes).  While canonize_delete runs,
+// these edges do not change -- it only adds deletion nodes and edges into them -- so one breadth-first pass serves every
+// query of the phase (723 walks over 400 000 nodes on the unthinned configs[3] region otherwise).
+void PoGraph::level_cache_build() {
+    level_cache_.assign(nodes.size(), -1);
+    std::vector<int> cur{0}, nxt;
+    level_cache_[0] = 0;
+    int level = 0;
+    while (!cur.empty()) {
+        level += 1;
+        nxt.clear();
+        for (int u : cur)
+            for (int o : nodes[u].out) {
+                if (nodes[o].st == ST_DEL) continue;
+                if (level_cache_[o] < 0) { level_cache_[o] = level; nxt.push_back(o); }
+                for (int s : nodes[o].sib) if (level_cache_[s] < 0) { level_cache_[s] = level; nxt.push_back(s); }
+            }
+        cur.swap(nxt);
+    }
+}
 int PoGraph::node_level_exclude_delete(int w) {
+    if (level_cache_on_ && w < (int)level_cache_.size() && level_cache_[w] >= 0) return level_cache_[w];
     std::vector<int> level_node, sub;
     int level = 0;
     int stamp = ++stamp_;
@@ -406,7 +429,7 @@ void PoGraph::canonize_delete_at_level(int i) {
             std::vector<int> ng;
             for (int t = dl - dd; t > 0; --t) {
                 int w = new_node(ST_DEL, "=");
-                nodes[w].pool.push_back({rid, rcn, "="});
+                nodes[w].pool.push_back({rid, rcn, intern("=")});
                 ng.push_back(w);
             }
             add_edge_gap_to(d.u, v0, ng);
@@ -416,10 +439,26 @@ void PoGraph::canonize_delete_at_level(int i) {
 }
 
 // cpp:963-1005
+int PoGraph::intern(const std::string& lab) {
+    auto it = lab_id_.find(lab);
+    if (it != lab_id_.end()) return it->second;
+    const int id = (int)labtab.size();
+    labtab.push_back(lab);
+    lab_id_.emplace(lab, id);
+    return id;
+}
+int PoGraph::concat(int a, int b) {
+    const unsigned long long key = ((unsigned long long)(unsigned)a << 32) | (unsigned)b;
+    auto it = lab_cat_.find(key);
+    if (it != lab_cat_.end()) return it->second;
+    const int id = intern(labtab[(size_t)a] + labtab[(size_t)b]);
+    lab_cat_.emplace(key, id);
+    return id;
+}
 void PoGraph::merge_read_pool(int u, int v) {
-    auto cmp = [](const PoolEnt& a, const PoolEnt& b) {
+    auto cmp = [this](const PoolEnt& a, const PoolEnt& b) {
         if (a.rid != b.rid) return a.rid < b.rid;
-        if (a.lab != b.lab) return a.lab < b.lab;
+        if (a.lab != b.lab) return labtab[(size_t)a.lab] < labtab[(size_t)b.lab];
         return a.cn < b.cn;
     };
     auto& pu = nodes[u].pool;
@@ -431,13 +470,13 @@ void PoGraph::merge_read_pool(int u, int v) {
     size_t i = 0, j = 0;
     while (i < pu.size() && j < pv.size()) {
         if (pu[i].rid == pv[j].rid) {
-            res.push_back({pu[i].rid, pu[i].cn, pu[i].lab + pv[j].lab});
+            res.push_back({pu[i].rid, pu[i].cn, concat(pu[i].lab, pv[j].lab)});
             i++; j++;
-        } else if (pu[i].rid < pv[j].rid) res.push_back(std::move(pu[i++]));
-        else res.push_back(std::move(pv[j++]));
+        } else if (pu[i].rid < pv[j].rid) res.push_back(pu[i++]);
+        else res.push_back(pv[j++]);
     }
-    while (i < pu.size()) res.push_back(std::move(pu[i++]));
-    while (j < pv.size()) res.push_back(std::move(pv[j++]));
+    res.insert(res.end(), pu.begin() + (long)i, pu.end());
+    res.insert(res.end(), pv.begin() + (long)j, pv.end());
     pu.swap(res);
 }
 // cpp:1007-1038
@@ -627,6 +666,7 @@ void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>&
         }
     }
     // reads with insertions / deletions: their private chains and the edges around them
+    const size_t n_class_events = ev.size();
     for (int r = 0; r < n; r++) {
         if (!complex_read[r]) continue;
         const AlignedRead& rd = R[r];
@@ -684,12 +724,20 @@ void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>&
             (void)u_is_end;
         }
     }
-    std::stable_sort(ev.begin(), ev.end(), [](const Event& a, const Event& b) {
+    auto ev_less = [](const Event& a, const Event& b) {
         if (a.rid != b.rid) return a.rid < b.rid;
         if (a.op != b.op) return a.op < b.op;
         if (a.t != b.t) return a.t < b.t;
         return a.kind < b.kind;
-    });
+    };
+    // the events of the reads were made in read and operation order: sort the few class events, merge (the same
+    // order as one stable sort of everything)
+    if (std::is_sorted(ev.begin() + (long)n_class_events, ev.end(), ev_less)) {
+        std::stable_sort(ev.begin(), ev.begin() + (long)n_class_events, ev_less);
+        std::inplace_merge(ev.begin(), ev.begin() + (long)n_class_events, ev.end(), ev_less);
+    } else {
+        std::stable_sort(ev.begin(), ev.end(), ev_less);
+    }
     // replay
     std::vector<int> class_node((size_t)glen * 8, -1);
     for (int i = 0; i < glen; i++) if (ref_code(i) < 8) class_node[(size_t)i * 8 + ref_code(i)] = i + 1;   // a gene base no read carries has no class
@@ -708,7 +756,7 @@ void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>&
             int prev = -1;
             for (char lab : ch.labels) {
                 const int w = new_node(ch.st, std::string(1, lab));
-                nodes[w].pool.push_back({ch.rid, R[ch.rid].cn, std::string(1, lab)});
+                nodes[w].pool.push_back({ch.rid, R[ch.rid].cn, intern(std::string(1, lab))});
                 if (prev >= 0) add_edge(prev, w);
                 ch.nodes.push_back(w);
                 prev = w;
@@ -728,7 +776,7 @@ void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>&
             if (w < 0) throw std::runtime_error("class without a node");
             auto& pool = nodes[w].pool;
             pool.reserve((size_t)T.count[cls]);
-            const std::string lab(1, T.sym[c]);
+            const int lab = intern(std::string(1, T.sym[c]));
             for (int x = T.off[cls]; x < T.off[cls + 1]; x++) pool.push_back({T.pool[x], R[T.pool[x]].cn, lab});
         }
 }
@@ -751,10 +799,14 @@ PoGraph::PoGraph(const std::string& G, const std::vector<AlignedRead>& R, const 
         if (nodes[i].lab == "$") break;
         canonize_insert_at_level(i);
     }
+    level_cache_build();
+    level_cache_on_ = true;
     for (int i = 0; i < (int)nodes.size(); ++i) {            // canonize_delete :742-752
         if (nodes[i].lab == "$") break;
         canonize_delete_at_level(i);
     }
+    level_cache_on_ = false;
+    std::vector<int>().swap(level_cache_);
     directional_merge(false);
     directional_merge(true);
     path_collapse();
@@ -809,7 +861,7 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
     for (int a = 0; a < f.n_nodes; a++) {
         const GNode& x = g.nodes[alive[a]];
         n_pool += x.pool.size(); n_out += x.out.size(); n_lab += x.lab.size();
-        for (const auto& e : x.pool) n_lab += e.lab.size();
+        (void)n_lab;                                             // read labels are stored once each (below)
     }
     f.pool_rid.reserve(n_pool); f.pool_cn.reserve(n_pool); f.out_node.reserve(n_out); f.labels.reserve(n_lab);
     f.ent_rid.reserve(n_pool); f.ent_cn.reserve(n_pool); f.ent_node.reserve(n_pool); f.ent_lab_off.reserve(n_pool);
@@ -841,6 +893,7 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
     f.level_node_ptr.push_back(0);
     f.level_ent_ptr.push_back(0);
     std::vector<int> rid_stamp;
+    std::vector<int> lab_off(g.labtab.size(), -1);
     while (!level_node.empty()) {
         int lrc = 0, end_pos = -1;
         for (size_t qi = 0; qi < level_node.size(); qi++) {
@@ -854,9 +907,14 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
                 for (const auto& e : x.pool) {
                     f.ent_rid.push_back(e.rid); f.ent_cn.push_back(e.cn);
                     f.ent_node.push_back(a);
-                    f.ent_lab_off.push_back((int)f.labels.size());
-                    f.ent_lab_len.push_back((int)e.lab.size());
-                    for (char c : e.lab) f.labels.push_back(code(c));
+                    // a label is coded where an entry first carries it (symbol codes are handed out in the order the
+                    // entries are walked) and shared by every later entry
+                    if (lab_off[(size_t)e.lab] < 0) {
+                        lab_off[(size_t)e.lab] = (int)f.labels.size();
+                        for (char c : g.labtab[(size_t)e.lab]) f.labels.push_back(code(c));
+                    }
+                    f.ent_lab_off.push_back(lab_off[(size_t)e.lab]);
+                    f.ent_lab_len.push_back((int)g.labtab[(size_t)e.lab].size());
                     if ((int)rid_stamp.size() <= e.rid) rid_stamp.resize((size_t)e.rid + 1, -1);
                     f.ent_first.push_back(rid_stamp[e.rid] != level);
                     rid_stamp[e.rid] = level;

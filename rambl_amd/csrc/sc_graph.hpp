@@ -11,16 +11,19 @@
 #include <cstdint>
 #include <functional>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace sc {
 
 enum { ST_MAT = 0, ST_MIS = 1, ST_INS = 2, ST_DEL = 3 };
 
+// One (read, label) entry of a node's read pool.  The label is an index into PoGraph::labtab: a pool of 10^5 entries
+// holds a handful of distinct labels, and entries are sorted, merged and moved far more often than they are read.
 struct PoolEnt {
     int rid;
     int cn;
-    std::string lab;
+    int lab;
 };
 
 struct GNode {
@@ -68,6 +71,7 @@ public:
     PoGraph(const std::string& G, const std::vector<AlignedRead>& R, const MsaFn& msa, const ThreadFn& thread);
 
     std::vector<GNode> nodes;
+    std::vector<std::string> labtab;       // distinct read labels; PoolEnt::lab indexes it
     int n_alive = 0;
     long msa_calls = 0;
 
@@ -77,6 +81,10 @@ public:
     int root() const { return 0; }
 
 private:
+    std::unordered_map<std::string, int> lab_id_;
+    std::unordered_map<unsigned long long, int> lab_cat_;
+    int intern(const std::string& lab);
+    int concat(int a, int b);              // id of labtab[a] + labtab[b]
     const MsaFn& msa_;
     int stamp_ = 0;
     std::vector<int> order_;   // alive node indices in `nodes` order (valid after finalize_ids)
@@ -97,6 +105,9 @@ private:
     void delete_edge_level(int i);
     void canonize_insert_at_level(int i);
     int node_level_exclude_delete(int w);
+    void level_cache_build();
+    std::vector<int> level_cache_;
+    bool level_cache_on_ = false;
     void find_delete_from(int w, std::vector<GapEx>& out);
     void canonize_delete_at_level(int i);
     void merge_read_pool(int u, int v);

@@ -38,12 +38,17 @@ def main():
     print("dataset %.1f s" % (time.time() - t0), flush=True)
     argv = ["-r", "deep4m:1-1500", "-q", "0", "-D", str(depth), "-I", "13", "-l", "70", "-t", "0.02", "-d", "0.02", "-w", "5000", fa, sam]
     runs = []
+    os.environ["SC_STATS"] = "1"
+    os.environ["SC_SYNC_LOG"] = "1"
     for rep in range(2):
         out, err = io.StringIO(), io.StringIO()
         t0 = time.time()
         rc = cli.main(argv, out=out, err=err)
         dt = time.time() - t0
         print("run %d: rc %d, %.1f s, max rss %.1f GB" % (rep, rc, dt, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0), flush=True)
+        for line in err.getvalue().splitlines():
+            if line.startswith("sc_stats"):
+                print(line[:1500], flush=True)
         if rc != 0:
             print(err.getvalue()[-2000:])
             return 1
