@@ -21,7 +21,9 @@
 #include <cstring>
 #include <memory>
 #include <numeric>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -147,9 +149,25 @@ bool load_sam_text(sc_aln& a, const char* text, size_t len) {
     return true;
 }
 
-// BGZF: a series of gzip members, each with the BC extra field; the payload is raw deflate (SAM spec 4.1)
+// BGZF: a series of gzip members, each with the BC extra field; the payload is raw deflate (SAM spec 4.1).
+// The members are independent: one pass over the headers finds where each one's bytes go, then the host threads
+// the process may use inflate them side by side.
+int inflate_threads() {
+    long quota = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {             // "<quota> <period>" or "max <period>"
+        long q = 0, per = 0;
+        if (fscanf(f, "%ld %ld", &q, &per) == 2 && q > 0 && per > 0) quota = (q + per - 1) / per;
+        fclose(f);
+    }
+    long n = (long)std::thread::hardware_concurrency();
+    if (quota > 0 && quota < n) n = quota;
+    if (const char* e = getenv("SC_INGEST_THREADS")) n = atol(e);
+    return (int)std::min<long>(std::max<long>(n, 1), 32);
+}
 bool inflate_bgzf(const unsigned char* src, size_t n, std::vector<unsigned char>& out, std::string& err) {
-    size_t o = 0;
+    struct Member { size_t cdata, clen, at; unsigned isize, crc; };
+    std::vector<Member> members;
+    size_t o = 0, total = 0;
     while (o + 18 <= n) {
         if (src[o] != 0x1f || src[o + 1] != 0x8b || src[o + 2] != 8 || !(src[o + 3] & 4)) { err = "not a BGZF block"; return false; }
         const unsigned xlen = src[o + 10] | (src[o + 11] << 8);
@@ -160,22 +178,36 @@ bool inflate_bgzf(const unsigned char* src, size_t n, std::vector<unsigned char>
             if (src[x] == 'B' && src[x + 1] == 'C' && slen == 2) bsize = (src[x + 4] | (src[x + 5] << 8)) + 1L;
             x += 4 + slen;
         }
-        if (bsize < 0 || o + (size_t)bsize > n) { err = "BGZF block without a BC field or truncated"; return false; }
-        const size_t cdata = o + 12 + xlen, clen = (size_t)bsize - xlen - 20;
+        if (bsize < (long)xlen + 20 || o + (size_t)bsize > n) { err = "BGZF block without a BC field or truncated"; return false; }
         const unsigned isize = src[o + bsize - 4] | (src[o + bsize - 3] << 8) | (src[o + bsize - 2] << 16) | ((unsigned)src[o + bsize - 1] << 24);
-        const size_t at = out.size();
-        out.resize(at + isize);
-        if (isize) {
-            z_stream zs{};
-            if (inflateInit2(&zs, -15) != Z_OK) { err = "zlib"; return false; }
-            zs.next_in = const_cast<unsigned char*>(src + cdata); zs.avail_in = (unsigned)clen;
-            zs.next_out = out.data() + at; zs.avail_out = isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END) { err = "corrupt BGZF block"; return false; }
-        }
+        const unsigned crc = src[o + bsize - 8] | (src[o + bsize - 7] << 8) | (src[o + bsize - 6] << 16) | ((unsigned)src[o + bsize - 5] << 24);
+        members.push_back(Member{o + 12 + xlen, (size_t)bsize - xlen - 20, total, isize, crc});
+        total += isize;
         o += (size_t)bsize;
     }
+    out.resize(total);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> bad{false};
+    auto work = [&]() {
+        for (size_t k = next.fetch_add(1); k < members.size() && !bad.load(std::memory_order_relaxed); k = next.fetch_add(1)) {
+            const Member& m = members[k];
+            if (!m.isize) { if (m.crc != 0u) { bad = true; return; } continue; }
+            z_stream zs{};
+            if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
+            zs.next_in = const_cast<unsigned char*>(src + m.cdata); zs.avail_in = (unsigned)m.clen;
+            zs.next_out = out.data() + m.at; zs.avail_out = m.isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = true; return; }
+            if ((unsigned)crc32(crc32(0L, Z_NULL, 0), out.data() + m.at, m.isize) != m.crc) { bad = true; return; }   // the member's CRC-32 of its data
+        }
+    };
+    const int nt = (int)std::min<size_t>((size_t)inflate_threads(), std::max<size_t>(members.size() / 4, 1));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    if (bad) { err = "corrupt BGZF block (inflate or CRC-32)"; return false; }
     return true;
 }
 

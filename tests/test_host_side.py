@@ -292,6 +292,30 @@ def _bgzf_block(payload):
             struct.pack("<H", bsize) + cdata + struct.pack("<I", zlib.crc32(payload) & 0xFFFFFFFF) + struct.pack("<I", len(payload)))
 
 
+@pytest.mark.parametrize("threads", ["1", "5"])
+def test_bam_of_many_bgzf_members_decodes_like_the_sam(threads, tmp_path, monkeypatch):
+    """A BAM of a few hundred BGZF members (inflated side by side by SC_INGEST_THREADS host threads) gives the records of
+    the SAM text it was written from, in the same order; a flipped bit in one member is reported, not decoded."""
+    from rambl_amd import capi, synth
+    monkeypatch.setenv("SC_INGEST_THREADS", threads)
+    gene = synth.make_gene(7, glen=1500, n_strains=3, n_reads=60000, name="g7")
+    fa, sam = synth.write_dataset(str(tmp_path), [gene])
+    bam = str(tmp_path / "reads.bam")
+    T.write_bam(sam, bam)
+    assert os.path.getsize(bam) > 300000                 # ~230 members of 60 000 bytes before compression
+    a, b = capi.NativeAln(sam), capi.NativeAln(bam)
+    assert a.records() == b.records() == 60000
+    seq = open(fa).read().split("\n", 1)[1].replace("\n", "")
+    ra, rb = a.load_reads(seq, "g7", 1, 1500, 0, 70, 13, 800), b.load_reads(seq, "g7", 1, 1500, 0, 70, 13, 800)
+    assert (ra.pos, ra.cigar, ra.seq, ra.copies, ra.mates) == (rb.pos, rb.cigar, rb.seq, rb.copies, rb.mates)
+    raw = bytearray(open(bam, "rb").read())
+    raw[len(raw) // 2] ^= 0x40
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(capi.StrainCallError):
+        capi.NativeAln(bad)
+
+
 def test_bam_decoder_on_hand_assembled_bytes(tmp_path):
     """The library's BGZF/BAM decoder (sc_aln_open) on bytes assembled field by field from the SAM specification (section
     4.2: block_size, refID, pos, l_read_name, mapq, bin, n_cigar_op, flag, l_seq, next_refID, next_pos, tlen, read_name,
