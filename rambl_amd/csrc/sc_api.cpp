@@ -44,6 +44,7 @@ int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, cons
 int level_kind(const LevelHdr& h);
 int level_table_capacity();
 void launch_level_batch(hipStream_t st, int kind, const LevelBatch& b, int n);
+void launch_level_any(hipStream_t st, const LevelBatch& b, int n);
 void launch_msa(hipStream_t st, const MsaDev& d);
 void launch_thread(hipStream_t st, const ThreadDev& d, int* pool_sorted);
 int init_kernels();
@@ -271,6 +272,7 @@ void Ctx::serve_levels() {
         w->wcv.notify_one();
     };
     unsigned idle_spins = 0;
+    const bool any_kind = !(getenv("SC_ANY_KIND") && atoi(getenv("SC_ANY_KIND")) == 0);
     for (;;) {
         if (n_pending.load(std::memory_order_acquire) > 0 || (waiting.empty() && flying.empty())) {
             std::unique_lock<std::mutex> lk(dmu);
@@ -303,9 +305,9 @@ void Ctx::serve_levels() {
             LevelBatch batch;
             Worker* who[MAXB];
             int n = 0;
-            bool timed = false;
+            bool timed = false, mixed = false;
             for (auto it = waiting.begin(); it != waiting.end() && n < MAXB;) {
-                if (it->kind != kind) { ++it; continue; }
+                if (it->kind != kind) { if (!any_kind) { ++it; continue; } mixed = true; }
                 batch.it[n] = it->item;
                 who[n++] = it->w;
                 timed = timed || it->timed;
@@ -313,7 +315,8 @@ void Ctx::serve_levels() {
             }
             hipStream_t st = lstreams[(size_t)fs].st;
             if (timed) for (int i = 0; i < n; i++) (void)hipEventRecord(who[i]->ev0, st);
-            launch_level_batch(st, kind, batch, n);
+            if (mixed) launch_level_any(st, batch, n);          // every waiting level, whatever variant it needs
+            else launch_level_batch(st, kind, batch, n);
             if (timed) for (int i = 0; i < n; i++) (void)hipEventRecord(who[i]->ev1, st);
             lstreams[(size_t)fs].busy = n;
             lstreams[(size_t)fs].unretired++;
@@ -758,7 +761,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         if (ctx->workers.size() == 1) {
             // a single region in flight: nobody to batch with, so the worker launches its level itself and watches the stamp
             LevelBatch batch;
-            batch.it[0] = LevelItem{jd_dev, H, Pm, Rd};
+            batch.it[0] = LevelItem{jd_dev, H, level_kind(H), Pm, Rd};
             hipStream_t ls = ctx->lstreams[0].st;
             if (timed) HIPCHK(hipEventRecord(ev0, ls));
             launch_level_batch(ls, level_kind(H), batch, 1);
@@ -777,7 +780,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 }
             }
         } else {
-            ctx->submit_level(LevelRequest{this, LevelItem{jd_dev, H, Pm, Rd}, level_kind(H), timed});
+            ctx->submit_level(LevelRequest{this, LevelItem{jd_dev, H, level_kind(H), Pm, Rd}, level_kind(H), timed});
             wait_level();
         }
         level_launches++;

@@ -85,12 +85,13 @@ struct LevelResult;
 struct LevelItem {
     const JobDev* job;           // device memory; constant while the region is walked
     LevelHdr h;
+    int kind;                    // level_kind(h): which variant of the level kernel serves it (k_level_any looks here)
     const LevelParams* P;        // host-mapped
     LevelResult* R;              // host-mapped
 };
 constexpr int MAXB = 48;
 struct LevelBatch { LevelItem it[MAXB]; };
-static_assert(sizeof(LevelBatch) <= 4096, "kernel-argument segment");
+static_assert(sizeof(LevelItem) == 80 && sizeof(LevelBatch) <= 4096, "kernel-argument segment");
 
 // Per-level results, written by the kernel into host-mapped pinned memory; `seq` last (system-scope release).
 struct LevelResult {

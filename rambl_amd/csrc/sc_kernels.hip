@@ -733,12 +733,20 @@ constexpr int CHAIN_THREADS = 512;   // eight wavefronts build the level
 // wavefronts that run the chain = window of 16 * NW draws: all eight while a lane's share of the strains is
 // small (the pass is latency-bound and a wider window accepts more draws), four otherwise (the others leave)
 constexpr int chain_nw(int nb) { return nb <= 2 ? 8 : 4; }
-template <int NB, bool ROWS_LDS>
-__global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(LevelBatch batch) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+// the level's scalars out of an item, whatever address space the item is read through (field by field: a struct in the
+// constant address space has no copy constructor)
+template <class IT>
+__device__ __forceinline__ LevelHdr load_hdr(const IT& it) {
+    LevelHdr h;
+    h.mode = it.h.mode; h.S = it.h.S; h.e0 = it.h.e0; h.e1 = it.h.e1; h.has_dups = it.h.has_dups; h.any_multi = it.h.any_multi;
+    h.Q = it.h.Q; h.n_sweeps = it.h.n_sweeps; h.n_copy = it.h.n_copy; h.do_update = it.h.do_update; h.done = it.h.done;
+    h.copy_n = it.h.copy_n; h.seq = it.h.seq;
+    return h;
+}
+template <int NB, bool ROWS_LDS, class IT>
+__device__ __forceinline__ void level_sample_body(const IT& it, unsigned char* s_raw) {
     const unsigned long long wall0 = wall_clock64();
-    const LevelItem& it = batch.it[blockIdx.x];
-    const LevelHdr& h = it.h;
+    const LevelHdr h = load_hdr(it);
     KJob& job = *(KJob*)it.job;
     const LevelParams* __restrict__ P = it.P;
     LevelResult* __restrict__ R = it.R;
@@ -840,11 +848,10 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(LevelBatch batch
 // --------------------------------------------------------------------------
 // a13 + a15: one level without the sampler in one launch -- the read log-likelihood update, and for MODE_HARD
 // the soft update hard_clustering (NonparametricClustering.cpp:17-125).  Single workgroup.
-__global__ __launch_bounds__(512) void k_level(LevelBatch batch) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+template <class IT>
+__device__ __forceinline__ void level_plain_body(const IT& it, unsigned char* s_raw) {
     const unsigned long long wall0 = wall_clock64();
-    const LevelItem& it = batch.it[blockIdx.x];
-    const LevelHdr& h = it.h;
+    const LevelHdr h = load_hdr(it);
     KJob& job = *(KJob*)it.job;
     const LevelParams* __restrict__ P = it.P;
     LevelResult* __restrict__ R = it.R;
@@ -968,6 +975,45 @@ __global__ __launch_bounds__(512) void k_level(LevelBatch batch) {
     __syncthreads();
     for (int i = tid; i < S * K2; i += nt) R->subst[i] = s_tab[i];
     finish_level(h, R, wall0, tid);
+}
+
+// One kernel per kind of level (a single region in flight launches its levels directly) ...
+template <int NB, bool ROWS_LDS>
+__global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(LevelBatch batch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    level_sample_body<NB, ROWS_LDS>(batch.it[blockIdx.x], s_raw);
+}
+__global__ __launch_bounds__(512) void k_level(LevelBatch batch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    level_plain_body(batch.it[blockIdx.x], s_raw);
+}
+// ... and one kernel for a batch of levels of ANY kind (many regions in flight: with one kind per launch, and a
+// stream held until its batch is done, the five or so kinds that wait at any time take turns for the free streams;
+// tools/launch_policy_sim.py).  Workgroup b looks at the kind of its item and calls the variant: the variants are
+// functions of their own (`noinline`: each keeps its own register allocation -- merged into one body they spilled
+// 56 scalars into the sampler's pass loop), reading the item through the constant address space like kernel arguments.
+typedef const __attribute__((address_space(4))) LevelItem KItem;
+template <int NB, bool ROWS_LDS>
+__device__ __noinline__ void level_sample_call(KItem* it) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    level_sample_body<NB, ROWS_LDS>(*it, s_raw);
+}
+__device__ __noinline__ void level_plain_call(KItem* it) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    level_plain_body(*it, s_raw);
+}
+__global__ __launch_bounds__(CHAIN_THREADS) void k_level_any(LevelBatch batch) {
+    KItem* it = (KItem*)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.x;      // batch is the only argument
+    const int kind = it->kind;
+    if (kind == 0) { level_plain_call(it); return; }
+    const bool wl = (kind - 1) & 1;
+#define SC_ANY(NB) case NB: if (wl) level_sample_call<NB, true>(it); else level_sample_call<NB, false>(it); break;
+    switch ((kind - 1) / 2 + 1) {
+        SC_ANY(1) SC_ANY(2) SC_ANY(3) SC_ANY(4) SC_ANY(5) SC_ANY(6) SC_ANY(7)
+        default: if (wl) level_sample_call<8, true>(it); else level_sample_call<8, false>(it);
+    }
+#undef SC_ANY
+    (void)batch;
 }
 // --------------------------------------------------------------------------
 // a7/a8: progressive sum-of-pairs MSA, MultipleSequenceAlignmentSP.cpp:10-301,
@@ -1297,6 +1343,7 @@ template <int NB, bool L> static int set_sample_attr() {
 }
 int init_kernels() {
     int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEVEL_LDS);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_any), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msa<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSA_LDS);
     rc |= set_sample_attr<1, true>(); rc |= set_sample_attr<1, false>();
     rc |= set_sample_attr<2, true>(); rc |= set_sample_attr<2, false>();
@@ -1350,6 +1397,10 @@ int level_kind(const LevelHdr& h) {
     int nb = (S + 15) / 16;
     nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
     return 1 + 2 * (nb - 1) + (wl ? 1 : 0);
+}
+// every item carries its kind (LevelItem::kind)
+void launch_level_any(hipStream_t st, const LevelBatch& b, int n) {
+    hipLaunchKernelGGL(k_level_any, dim3(n), dim3(CHAIN_THREADS), CHAIN_LDS, st, b);
 }
 void launch_level_batch(hipStream_t st, int kind, const LevelBatch& b, int n) {
     if (kind == 0) {

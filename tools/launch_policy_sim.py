@@ -25,17 +25,24 @@ def sim(policy, R=100, NS=11, T=3000.0, seed=1, maxb=48):
             fs=[i for i in range(NS) if streams[i]==0]
             ks=[k for k in waiting if waiting[k]]
             if not fs or not ks: return
-            if policy=="oldest": k=min(ks,key=lambda k: waiting[k][0][0])
+            if policy in ("oldest","anykind"): k=min(ks,key=lambda k: waiting[k][0][0])
             elif policy=="largest": k=max(ks,key=lambda k: len(waiting[k]))
             elif policy=="aged":
                 old=[k for k in ks if now-waiting[k][0][0]>0.5]
                 k=min(old,key=lambda k: waiting[k][0][0]) if old else max(ks,key=lambda k: len(waiting[k]))
             elif policy=="shortfirst": k=min(ks)   # plain first, then nb1...
-            b=waiting[k][:maxb]; waiting[k]=waiting[k][maxb:]
+            if policy=="anykind":                  # one kernel serves every kind: all waiting levels leave together
+                b=[]
+                for k2 in ks:
+                    b+=[(tr,r,k2) for (tr,r) in waiting[k2]]; waiting[k2]=[]
+                b.sort(); rest=b[maxb:]; b=b[:maxb]
+                for (tr,r,k2) in rest: waiting[k2].append((tr,r))
+            else:
+                b=[(tr,r,k) for (tr,r) in waiting[k][:maxb]]; waiting[k]=waiting[k][maxb:]
             s=fs[0]; streams[s]=len(b); nlaunch+=1
-            for (tr,r) in b:
+            for (tr,r,k2) in b:
                 wait_sum+=now-tr
-                d=kinds[k][2]*rnd.uniform(0.85,1.25)+0.03
+                d=kinds[k2][2]*rnd.uniform(0.85,1.25)+0.03
                 heapq.heappush(ev,(now+d,"fin",(r,s)))
     while ev:
         t,typ,data=heapq.heappop(ev)
@@ -47,7 +54,7 @@ def sim(policy, R=100, NS=11, T=3000.0, seed=1, maxb=48):
             heapq.heappush(ev,(t+ (0.25 if rnd.random()<0.25 else 0.02),"req",r))
             try_launch(t)
     return done/T, wait_sum/max(done,1), done/max(nlaunch,1)
-for pol in ("oldest","largest","aged","shortfirst"):
+for pol in ("oldest","largest","aged","shortfirst","anykind"):
     for ns in (11,):
         print(pol, ns, ["%.3f"%x for x in sim(pol,NS=ns)])
 print("streams 16 oldest", ["%.3f"%x for x in sim("oldest",NS=16)])
