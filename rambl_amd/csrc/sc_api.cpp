@@ -260,8 +260,9 @@ void Worker::init() {
 //   * A level's kernel stores its stamp into host memory after everything else it reports (system-scope release):
 //     completion is seen without a stream synchronisation.
 //   * Launch streams are shared by all regions.  A stream carries one batch at a time, so kernels of different
-//     regions never queue behind each other; while a stream is free, the oldest waiting level and every other waiting
-//     level that needs the same kernel (up to MAXB) leave together as one grid (workgroup b = region b of the batch).
+//     regions never queue behind each other; while a stream is free, every waiting level (up to MAXB) leaves as one
+//     grid, workgroup b = region b of the batch: the kernel of their kind when they all need the same one, k_level_any
+//     (which calls the variant each item names) otherwise.  SC_ANY_KIND=0 keeps one kind per launch (measurements).
 void Ctx::serve_levels() {
     (void)hipSetDevice(device);
     std::deque<LevelRequest> waiting;          // taken from `pending`, not launched yet
