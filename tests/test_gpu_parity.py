@@ -421,6 +421,40 @@ def test_config3_hundred_regions_match_reference(tmp_path):
     assert full.count(">") == meta["contigs"]
 
 
+def test_mixed_kinds_in_one_batch_match_the_fixtures(tmp_path):
+    """Regions of very different shapes in flight together, so that one launch of the level server carries levels that
+    need different variants of the level kernel (k_level_any): the 50-strain region of config4_deep (up to 100+
+    candidates per level: the widest sampler variants, weight rows in HBM) next to the small golden cases (a few
+    candidates, levels without sampler, a gene with IUPAC codes).  Every region's FASTA must equal the reference's own
+    output for it, whoever it shared its launches with."""
+    import hashlib
+    import json
+    from rambl_amd import capi, cli, stage5, synth
+    from test_oracle_golden import load_case
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    prepared, expected = [], []
+    meta = json.load(open(os.path.join(gold, "config4_deep", "meta.json")))
+    gene = synth.make_gene(4, glen=1500, n_strains=50, n_reads=100000, name="deep4")
+    fa, sam = synth.write_dataset(str(tmp_path / "deep"), [gene])
+    assert hashlib.sha256(open(sam, "rb").read()).hexdigest() == meta["sam_sha256"]
+    for rep in range(2):                                       # twice: the wide variants also meet each other
+        pa = cli.parse_cmd_line(meta["argv"] + [fa, sam])
+        prepared.append((pa, cli.load_regions(pa)))
+        expected.append(open(os.path.join(gold, "config4_deep", "expected.fa")).read())
+    for k, name in enumerate(_golden_cases()):
+        d = tmp_path / ("g%d" % k)
+        d.mkdir()
+        args, exp_fa, _, _ = load_case(name, str(d))
+        pa = cli.parse_cmd_line(args)
+        prepared.append((pa, cli.load_regions(pa)))
+        expected.append(exp_fa)
+    errors = []
+    with capi.Context(0, len(prepared)) as ctx:
+        texts, _ = stage5.run_regions(ctx, prepared, len(prepared), None, errors)
+    assert errors == []
+    assert [i for i, (g, e) in enumerate(zip(texts, expected)) if g != e] == []
+
+
 @pytest.fixture(scope="module")
 def million_reads(tmp_path_factory):
     """BASELINE.json configs[3] at its stated size: 1 000 000 x 150 bp reads, 50 strains, one 1 500 bp gene."""
