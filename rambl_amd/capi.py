@@ -145,25 +145,32 @@ class NativeReads:
         raw = C.string_at(text, off[self.n]) if self.n else b""
         return [raw[off[i]:off[i + 1]].decode("ascii") for i in range(self.n)]
 
+    def _view(self, name, build):
+        """The list views are built once (an access inside a loop would otherwise rebuild the whole list every time)."""
+        cache = self.__dict__.setdefault("_views", {})
+        if name not in cache:
+            cache[name] = build()
+        return cache[name]
+
     @property
     def pos(self):
-        return [self._pos[i] for i in range(self.n)]
+        return self._view("pos", lambda: [self._pos[i] for i in range(self.n)])
 
     @property
     def copies(self):
-        return [self._cn[i] for i in range(self.n)]
+        return self._view("copies", lambda: [self._cn[i] for i in range(self.n)])
 
     @property
     def cigar(self):
-        return self._texts(self._cig, self._cig_off)
+        return self._view("cigar", lambda: self._texts(self._cig, self._cig_off))
 
     @property
     def seq(self):
-        return self._texts(self._seq, self._seq_off)
+        return self._view("seq", lambda: self._texts(self._seq, self._seq_off))
 
     @property
     def mates(self):
-        return [[self._mate_idx[k] for k in range(self._mate_off[i], self._mate_off[i + 1])] for i in range(self.n)]
+        return self._view("mates", lambda: [[self._mate_idx[k] for k in range(self._mate_off[i], self._mate_off[i + 1])] for i in range(self.n)])
 
 
 class NativeAln:
