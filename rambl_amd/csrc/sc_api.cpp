@@ -61,22 +61,68 @@ static double now_ms() {
 }
 
 // growable device buffer
+// A device buffer that only grows.  While regions are in flight nothing is handed back to the driver: hipFree waits for
+// the device and unmapping memory suspends every queue of the process for tens of milliseconds (seen as level kernels of
+// ALL regions in flight lasting ~30 ms at once, a few times per region, when each new region's larger arrays were freed
+// and allocated again).  An outgrown buffer is kept until the worker goes; growth is geometric, so that is at most as
+// much again -- nothing next to 288 GB.
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
+    std::vector<void*> outgrown;
     void* ensure(size_t n) {
         if (n > cap) {
-            if (p) (void)hipFree(p);
-            size_t want = n + n / 4 + 256;
+            static const bool keep = !(getenv("SC_DEVBUF_KEEP") && atoi(getenv("SC_DEVBUF_KEEP")) == 0);
+            if (p) { if (keep) outgrown.push_back(p); else (void)hipFree(p); }
+            size_t want = keep ? std::max<size_t>(n + n / 2 + 4096, 2 * cap) : n + n / 4 + 256;
             HIPCHK(hipMalloc(&p, want));
             cap = want;
         }
         return p;
     }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) (void)hipFree(p); for (void* q : outgrown) (void)hipFree(q); }
 };
-template <class T> static T* upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) {
+// Pinned staging for a region's transfers.  A copy between the device and ordinary (pageable) host memory makes the
+// runtime pin those pages for the copy and let them go afterwards; with regions in flight that costs far more than the
+// copy -- registering and releasing user pages suspends every queue of the process (level kernels of ALL regions lasting
+// ~30 ms at once, a few times per region).  So every sizeable transfer goes through page-locked memory the worker owns:
+// grow-only chunks, handed out by a bump pointer, reused by the next region.
+struct PinnedArena {
+    struct Chunk { char* p; size_t cap, used; };
+    struct Back { void* dst; const void* src; size_t n; };      // device-to-host copies still to be moved to their vectors
+    std::vector<Chunk> chunks;
+    std::vector<Back> back;
+    bool on = true;                   // false: pass the copies through (a single region in flight suspends nobody)
+    void* take(size_t n) {
+        n = (n + 255) & ~(size_t)255;
+        for (Chunk& c : chunks) if (c.cap - c.used >= n) { void* r = c.p + c.used; c.used += n; return r; }
+        size_t cap = std::max<size_t>(n, (size_t)8 << 20);
+        if (!chunks.empty()) cap = std::max(cap, 2 * chunks.back().cap);
+        char* q = nullptr;
+        HIPCHK(hipHostMalloc((void**)&q, cap, hipHostMallocDefault));
+        chunks.push_back(Chunk{q, cap, n});
+        return q;
+    }
+    void reset() { for (Chunk& c : chunks) c.used = 0; back.clear(); }
+    void h2d(void* dst, const void* src, size_t n, hipStream_t st) {
+        if (n == 0) return;
+        if (!on || n < 4096) { HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st)); return; }
+        void* q = take(n);
+        memcpy(q, src, n);
+        HIPCHK(hipMemcpyAsync(dst, q, n, hipMemcpyHostToDevice, st));
+    }
+    void d2h(void* dst, const void* src, size_t n, hipStream_t st) {          // complete after the stream's synchronisation + land()
+        if (n == 0) return;
+        if (!on || n < 4096) { HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st)); return; }
+        void* q = take(n);
+        HIPCHK(hipMemcpyAsync(q, src, n, hipMemcpyDeviceToHost, st));
+        back.push_back(Back{dst, q, n});
+    }
+    void land() { for (const Back& b : back) memcpy(b.dst, b.src, b.n); back.clear(); }
+    ~PinnedArena() { for (Chunk& c : chunks) (void)hipHostFree(c.p); }
+};
+template <class T> static T* upload(PinnedArena& ar, DevBuf& b, const std::vector<T>& v, hipStream_t st) {
     T* d = (T*)b.ensure(std::max<size_t>(v.size(), 1) * sizeof(T));
-    if (!v.empty()) HIPCHK(hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    ar.h2d(d, v.data(), v.size() * sizeof(T), st);
     return d;
 }
 
@@ -163,6 +209,13 @@ struct LevelRequest { Worker* w; LevelItem item; int kind; bool timed; };
 struct LaunchStream { hipStream_t st = nullptr; int busy = 0; int unretired = 0; };
 struct Ctx {
     int device = 0;
+    // page-locked staging arenas, shared: a region holds one only while it is set up, so a handful serves any number in flight
+    std::mutex amu;
+    std::condition_variable acv;
+    std::vector<PinnedArena*> arenas, free_arenas;
+    int arena_limit = 0;              // 0: staging off (one region in flight, or SC_PINNED_STAGING=0)
+    PinnedArena* lease_arena(PinnedArena* passthrough);
+    void release_arena(PinnedArena* a);
     std::string last_error;
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
@@ -231,6 +284,9 @@ struct Worker {
         b_ll, b_has, b_isnew, b_tabA, b_tabLf, b_qcode, b_qent, b_quid, b_out_ptr, b_out_node, b_pool_ptr, b_pool_rid,
         b_pool_cn, b_isend, b_esrc, b_support, b_jobdev;
     DevBuf m_seqs, m_off, m_cols0, m_cols1, m_counts, m_moves, m_trace, m_out, m_edge;
+    PinnedArena* stage = nullptr;     // page-locked staging of the region's uploads / downloads: leased from the context
+                                      // for the region's set-up (Ctx::lease_arena), handed back when its copies have landed
+    PinnedArena passthrough;          // on = false
     DevBuf t_ref, t_pos, t_seqoff, t_seq, t_cigoff, t_cigop, t_ciglen, t_lut, t_tabs, t_pool, t_pool2;
 
     void init();
@@ -263,6 +319,19 @@ void Worker::init() {
 //     regions never queue behind each other; while a stream is free, every waiting level (up to MAXB) leaves as one
 //     grid, workgroup b = region b of the batch: the kernel of their kind when they all need the same one, k_level_any
 //     (which calls the variant each item names) otherwise.  SC_ANY_KIND=0 keeps one kind per launch (measurements).
+PinnedArena* Ctx::lease_arena(PinnedArena* passthrough) {
+    if (arena_limit <= 0) { passthrough->on = false; return passthrough; }
+    std::unique_lock<std::mutex> lk(amu);
+    for (;;) {
+        if (!free_arenas.empty()) { PinnedArena* a = free_arenas.back(); free_arenas.pop_back(); a->reset(); return a; }
+        if ((int)arenas.size() < arena_limit) { PinnedArena* a = new PinnedArena(); arenas.push_back(a); return a; }
+        acv.wait(lk);
+    }
+}
+void Ctx::release_arena(PinnedArena* a) {
+    { std::lock_guard<std::mutex> lk(amu); free_arenas.push_back(a); }
+    acv.notify_one();
+}
 void Ctx::serve_levels() {
     (void)hipSetDevice(device);
     std::deque<LevelRequest> waiting;          // taken from `pending`, not launched yet
@@ -445,18 +514,18 @@ void Worker::thread_device(const std::string& G, const std::vector<AlignedRead>&
     ThreadDev d{};
     d.glen = glen; d.n_reads = n;
     char* dref = (char*)t_ref.ensure((size_t)glen + 1);
-    HIPCHK(hipMemcpyAsync(dref, G.data(), (size_t)glen, hipMemcpyHostToDevice, st));
+    stage->h2d(dref, G.data(), (size_t)glen, st);
     d.ref = dref;
-    d.pos = upload(t_pos, pos, st);
-    d.seq_off = upload(t_seqoff, seq_off, st);
+    d.pos = upload(*stage, t_pos, pos, st);
+    d.seq_off = upload(*stage, t_seqoff, seq_off, st);
     char* dseq = (char*)t_seq.ensure(seq.size() + 1);
-    if (!seq.empty()) HIPCHK(hipMemcpyAsync(dseq, seq.data(), seq.size(), hipMemcpyHostToDevice, st));
+    stage->h2d(dseq, seq.data(), seq.size(), st);
     d.seq = dseq;
-    d.cig_off = upload(t_cigoff, cig_off, st);
+    d.cig_off = upload(*stage, t_cigoff, cig_off, st);
     char* dop = (char*)t_cigop.ensure(cig_op.size() + 1);
-    if (!cig_op.empty()) HIPCHK(hipMemcpyAsync(dop, cig_op.data(), cig_op.size(), hipMemcpyHostToDevice, st));
+    stage->h2d(dop, cig_op.data(), cig_op.size(), st);
     d.cig_op = dop;
-    d.cig_len = upload(t_ciglen, cig_len, st);
+    d.cig_len = upload(*stage, t_ciglen, cig_len, st);
     uint8_t* dlut = (uint8_t*)t_lut.ensure(256);
     HIPCHK(hipMemcpyAsync(dlut, T.lut, 256, hipMemcpyHostToDevice, st));
     d.lut = dlut;
@@ -474,16 +543,17 @@ void Worker::thread_device(const std::string& G, const std::vector<AlignedRead>&
     T.count.resize(ncls); T.minrid.resize(ncls); T.smin.resize(ncls); T.emin.resize(ncls);
     T.tmin.resize((size_t)ncls * 8); T.off.resize((size_t)ncls + 1); T.pool.resize((size_t)m_bases);
     int err = 0;
-    HIPCHK(hipMemcpyAsync(T.count.data(), d.count, sizeof(int) * (size_t)ncls, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(T.minrid.data(), d.minrid, sizeof(int) * (size_t)ncls, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(T.smin.data(), d.smin, sizeof(int) * (size_t)ncls, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(T.emin.data(), d.emin, sizeof(int) * (size_t)ncls, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(T.tmin.data(), d.tmin, sizeof(int) * (size_t)ncls * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(T.off.data(), d.off, sizeof(int) * ((size_t)ncls + 1), hipMemcpyDeviceToHost, st));
-    if (m_bases > 0) HIPCHK(hipMemcpyAsync(T.pool.data(), pool_sorted, sizeof(int) * (size_t)m_bases, hipMemcpyDeviceToHost, st));
+    stage->d2h(T.count.data(), d.count, sizeof(int) * (size_t)ncls, st);
+    stage->d2h(T.minrid.data(), d.minrid, sizeof(int) * (size_t)ncls, st);
+    stage->d2h(T.smin.data(), d.smin, sizeof(int) * (size_t)ncls, st);
+    stage->d2h(T.emin.data(), d.emin, sizeof(int) * (size_t)ncls, st);
+    stage->d2h(T.tmin.data(), d.tmin, sizeof(int) * (size_t)ncls * 8, st);
+    stage->d2h(T.off.data(), d.off, sizeof(int) * ((size_t)ncls + 1), st);
+    stage->d2h(T.pool.data(), pool_sorted, sizeof(int) * (size_t)std::max<long>(m_bases, 0), st);
     HIPCHK(hipMemcpyAsync(&err, d.err, sizeof(int), hipMemcpyDeviceToHost, st));
     const double t_sync0 = now_ms();
     HIPCHK(hipStreamSynchronize(st));
+    stage->land();
     if (getenv("SC_SYNC_LOG")) fprintf(stderr, "sync thread_device %.3f ms\n", now_ms() - t_sync0);
     if (err) throw ScError(SC_ERR_ARG, "a read runs outside the window or past its own bases");
     const int INF = 0x7fffffff;
@@ -578,15 +648,15 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
 
     // ---- upload the static arrays
     JobDev jd{};
-    jd.ent_rid = upload(b_ent_rid, f.ent_rid, st);
-    jd.ent_cn = upload(b_ent_cn, f.ent_cn, st);
-    jd.ent_lab_off = upload(b_ent_lab_off, f.ent_lab_off, st);
-    jd.ent_lab_len = upload(b_ent_lab_len, f.ent_lab_len, st);
-    jd.ent_first = upload(b_ent_first, f.ent_first, st);
-    jd.ent_qoff = upload(b_ent_qoff, ent_qoff, st);
-    jd.labels = upload(b_labels, f.labels, st);
-    jd.mate_ptr = upload(b_mate_ptr, job.mate_off, st);
-    jd.mate_idx = upload(b_mate_idx, job.mate_idx, st);
+    jd.ent_rid = upload(*stage, b_ent_rid, f.ent_rid, st);
+    jd.ent_cn = upload(*stage, b_ent_cn, f.ent_cn, st);
+    jd.ent_lab_off = upload(*stage, b_ent_lab_off, f.ent_lab_off, st);
+    jd.ent_lab_len = upload(*stage, b_ent_lab_len, f.ent_lab_len, st);
+    jd.ent_first = upload(*stage, b_ent_first, f.ent_first, st);
+    jd.ent_qoff = upload(*stage, b_ent_qoff, ent_qoff, st);
+    jd.labels = upload(*stage, b_labels, f.labels, st);
+    jd.mate_ptr = upload(*stage, b_mate_ptr, job.mate_off, st);
+    jd.mate_idx = upload(*stage, b_mate_idx, job.mate_idx, st);
     jd.n_reads = n_reads; jd.K = K; jd.code_N = f.code_N;
     jd.ll_stride = ((long)n_reads + 3) & ~3L;
     jd.ll = (double*)b_ll.ensure(sizeof(double) * (size_t)jd.ll_stride * MAXS);
@@ -609,20 +679,23 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     {
         std::vector<int> esrc(f.out_node.size());
         for (int a = 0; a < f.n_nodes; a++) for (int x = f.out_ptr[a]; x < f.out_ptr[a + 1]; x++) esrc[x] = a;
-        int* d_out_ptr = upload(b_out_ptr, f.out_ptr, st);
-        int* d_out_node = upload(b_out_node, f.out_node, st);
-        int* d_pool_ptr = upload(b_pool_ptr, f.pool_ptr, st);
-        int* d_pool_rid = upload(b_pool_rid, f.pool_rid, st);
-        int* d_pool_cn = upload(b_pool_cn, f.pool_cn, st);
-        uint8_t* d_isend = upload(b_isend, f.node_is_end, st);
-        int* d_esrc = upload(b_esrc, esrc, st);
+        int* d_out_ptr = upload(*stage, b_out_ptr, f.out_ptr, st);
+        int* d_out_node = upload(*stage, b_out_node, f.out_node, st);
+        int* d_pool_ptr = upload(*stage, b_pool_ptr, f.pool_ptr, st);
+        int* d_pool_rid = upload(*stage, b_pool_rid, f.pool_rid, st);
+        int* d_pool_cn = upload(*stage, b_pool_cn, f.pool_cn, st);
+        uint8_t* d_isend = upload(*stage, b_isend, f.node_is_end, st);
+        int* d_esrc = upload(*stage, b_esrc, esrc, st);
         int* d_sup = (int*)b_support.ensure(sizeof(int) * std::max<size_t>(esrc.size(), 1));
         launch_edge_support(st, d_out_ptr, d_out_node, d_pool_ptr, d_pool_rid, d_pool_cn, d_isend, d_esrc, (int)esrc.size(),
                             f.pools_sorted ? 1 : 0, d_sup);
         if (!esrc.empty())
-            HIPCHK(hipMemcpyAsync(f.out_support.data(), d_sup, sizeof(int) * esrc.size(), hipMemcpyDeviceToHost, st));
+            stage->d2h(f.out_support.data(), d_sup, sizeof(int) * esrc.size(), st);
         const double t_sync0 = now_ms();
         HIPCHK(hipStreamSynchronize(st));
+        stage->land();
+        if (stage != &passthrough) ctx->release_arena(stage);      // every transfer of the set-up is done
+        stage = &passthrough;
         if (getenv("SC_SYNC_LOG")) fprintf(stderr, "sync uploads+edge_support %.3f ms (since cluster start %.3f)\n", now_ms() - t_sync0, now_ms() - t_cluster0);
         job.edge_support = f.out_support;
     }
@@ -1060,6 +1133,12 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
 
 void Worker::process(Job& job) {
     const double t0 = now_ms();
+    // page-locked staging for the set-up of this region; cluster() hands it back once the last copy has landed
+    struct Lease {
+        Worker* w;
+        ~Lease() { if (w->stage && w->stage != &w->passthrough) w->ctx->release_arena(w->stage); w->stage = nullptr; }
+    } lease{this};
+    stage = ctx->lease_arena(&passthrough);
     MsaFn msa = [this](const std::vector<std::string>& seqs, std::vector<std::string>& rows) { return msa_device(seqs, rows); };
     ThreadFn thr = [this, &job](const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cg,
                           ThreadTables& T) {
@@ -1171,6 +1250,11 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         if (e && !std::strcmp(e, "spin")) ctx->wait_mode = WAIT_SPIN;
         else if (e && !std::strcmp(e, "sleep")) ctx->wait_mode = WAIT_SLEEP;
         else ctx->wait_mode = ((double)stream_count + 2 <= 0.6 * cpu_budget()) ? WAIT_SPIN : WAIT_SLEEP;
+        // page-locked staging of the regions' transfers: only worth it while other regions are in flight (it is their queues
+        // that a pageable copy suspends); as many arenas as regions can be set up at once on this process's cores
+        const char* ps = getenv("SC_PINNED_STAGING");
+        const bool want = ps ? atoi(ps) != 0 : stream_count > 1;
+        ctx->arena_limit = want ? (int)std::min<double>(std::max(cpu_budget(), 2.0), 32.0) : 0;
     }
     for (int i = 0; i < stream_count; i++) {
         auto w = std::make_unique<Worker>();
@@ -1206,6 +1290,8 @@ void sc_ctx_destroy(sc_ctx* h) {
     for (auto& ls : ctx->lstreams) if (ls.st) (void)hipStreamDestroy(ls.st);
     for (auto& ss : ctx->setup_streams) if (ss) (void)hipStreamDestroy(ss);
 
+    for (PinnedArena* a : ctx->arenas) delete a;
+    ctx->arenas.clear(); ctx->free_arenas.clear();
     if (ctx->dU) (void)hipFree(ctx->dU);
     if (ctx->dUf) (void)hipFree(ctx->dUf);
     delete h;
