@@ -61,11 +61,10 @@ static double now_ms() {
 }
 
 // growable device buffer
-// A device buffer that only grows.  While regions are in flight nothing is handed back to the driver: hipFree waits for
-// the device and unmapping memory suspends every queue of the process for tens of milliseconds (seen as level kernels of
-// ALL regions in flight lasting ~30 ms at once, a few times per region, when each new region's larger arrays were freed
-// and allocated again).  An outgrown buffer is kept until the worker goes; growth is geometric, so that is at most as
-// much again -- nothing next to 288 GB.
+// A device buffer that only grows.  While regions are in flight nothing is handed back to the driver (hipFree waits for
+// the device): an outgrown buffer is kept until the worker goes; growth is geometric, so that is at most as much again --
+// nothing next to 288 GB.  (Measured: no difference to freeing at once; the stalls under load came from pageable copies,
+// see PinnedArena.  SC_DEVBUF_KEEP=0 restores the old behaviour.)
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     std::vector<void*> outgrown;
