@@ -173,16 +173,20 @@ bool inflate_bgzf(const unsigned char* src, size_t n, std::vector<unsigned char>
         const unsigned xlen = src[o + 10] | (src[o + 11] << 8);
         size_t x = o + 12, xe = x + xlen;
         long bsize = -1;
-        while (x + 4 <= xe && xe <= n) {
+        if (xe + 8 > n) { err = "truncated BGZF block"; return false; }
+        while (x + 4 <= xe) {
             const unsigned slen = src[x + 2] | (src[x + 3] << 8);
+            if (x + 4 + slen > xe) break;                                 // a subfield that runs past the extra field: not ours to read
             if (src[x] == 'B' && src[x + 1] == 'C' && slen == 2) bsize = (src[x + 4] | (src[x + 5] << 8)) + 1L;
             x += 4 + slen;
         }
         if (bsize < (long)xlen + 20 || o + (size_t)bsize > n) { err = "BGZF block without a BC field or truncated"; return false; }
         const unsigned isize = src[o + bsize - 4] | (src[o + bsize - 3] << 8) | (src[o + bsize - 2] << 16) | ((unsigned)src[o + bsize - 1] << 24);
         const unsigned crc = src[o + bsize - 8] | (src[o + bsize - 7] << 8) | (src[o + bsize - 6] << 16) | ((unsigned)src[o + bsize - 5] << 24);
+        if (isize > 65536u) { err = "BGZF block claims more than 64 KiB of data"; return false; }      // SAM spec 4.1
         members.push_back(Member{o + 12 + xlen, (size_t)bsize - xlen - 20, total, isize, crc});
         total += isize;
+        if (total > ((size_t)1 << 40)) { err = "BGZF file larger than this reader accepts"; return false; }
         o += (size_t)bsize;
     }
     out.resize(total);
@@ -364,13 +368,16 @@ int sc_aln_open(const char* path, sc_aln** out) {
         a->map = mmap(nullptr, a->map_len, PROT_READ, MAP_PRIVATE, fd, 0);
         if (a->map == MAP_FAILED) { a->map = nullptr; close(fd); return SC_ERR_INTERNAL; }
         const unsigned char* b = (const unsigned char*)a->map;
-        if (a->map_len >= 2 && b[0] == 0x1f && b[1] == 0x8b) {
-            ok = load_bam(*a, b, a->map_len);
-            munmap(a->map, a->map_len);            // every string was copied out
-            a->map = nullptr;
-        } else {
-            ok = load_sam_text(*a, (const char*)a->map, a->map_len);
-        }
+        try {
+            if (a->map_len >= 2 && b[0] == 0x1f && b[1] == 0x8b) {
+                ok = load_bam(*a, b, a->map_len);
+                munmap(a->map, a->map_len);            // every string was copied out
+                a->map = nullptr;
+            } else {
+                ok = load_sam_text(*a, (const char*)a->map, a->map_len);
+            }
+        } catch (const std::bad_alloc&) { a->error = "out of memory while reading the alignments"; ok = false; }
+        catch (const std::exception& ex) { a->error = ex.what(); ok = false; }
     }
     close(fd);
     *out = a.release();
@@ -379,7 +386,13 @@ int sc_aln_open(const char* path, sc_aln** out) {
 
 void sc_aln_close(sc_aln* a) { delete a; }
 
-const char* sc_aln_error(sc_aln* a) { return a ? a->error.c_str() : ""; }
+// The message of the last failing call of THIS thread on any handle (windows are ingested side by side on several
+// threads: a message kept on the shared handle could be another window's); the handle itself keeps what sc_aln_open said.
+static thread_local std::string tl_error;
+const char* sc_aln_error(sc_aln* a) {
+    if (!tl_error.empty()) return tl_error.c_str();
+    return a ? a->error.c_str() : "";
+}
 
 long sc_aln_records(sc_aln* a) { return a ? a->n_records : 0; }
 
@@ -439,10 +452,12 @@ int sc_aln_pileup_flags(sc_aln* a, const char* gene, int P, int Q, int mq, unsig
                     }
                     p += ln;
                 } else if (op == 'D' || op == 'N') {
+                    // a deleted base prints '*' (read as a deletion mark, StrainCall.cpp:712-735); a reference skip (N)
+                    // prints '>' or '<', which window_adjust does not look for: it only counts towards the coverage
                     const int lo = std::max(p, P), hi = std::min(p + ln - 1, Q);
                     if (lo <= hi) {
                         diff[(size_t)(lo - P)]++; diff[(size_t)(hi - P + 1)]--;
-                        memset(has_del + (lo - P), 1, (size_t)(hi - lo + 1));
+                        if (op == 'D') memset(has_del + (lo - P), 1, (size_t)(hi - lo + 1));
                     }
                     p += ln;
                 }
@@ -461,6 +476,7 @@ int sc_aln_pileup_flags(sc_aln* a, const char* gene, int P, int Q, int mq, unsig
 int sc_aln_load_reads(sc_aln* a, const char* gene, int p0, int p1, int mq, int rl, int max_ins, int max_depth, sc_reads** out) {
     if (!a || !gene || !out) return SC_ERR_ARG;
     *out = nullptr;
+    tl_error.clear();
     std::unique_ptr<sc_reads> R(new sc_reads());
     // ---- samtools view -q mq -F 1804 gene:p0-p1
     std::vector<const Rec*> view;
@@ -476,7 +492,7 @@ int sc_aln_load_reads(sc_aln* a, const char* gene, int p0, int p1, int mq, int r
     std::vector<Op> ops;
     int depth = 0;
     for (const Rec* r : view) {
-        if (!parse_cigar(r->cigar, r->clen, ops)) { a->error = "malformed CIGAR"; return SC_ERR_ARG; }
+        if (!parse_cigar(r->cigar, r->clen, ops)) { tl_error = "malformed CIGAR"; return SC_ERR_ARG; }
         int len = 0;
         for (const Op& o : ops) if (o.op == 'M' || o.op == 'D') len += o.len;
         const int r0 = r->pos, r1 = r0 + len - 1;
@@ -511,7 +527,7 @@ int sc_aln_load_reads(sc_aln* a, const char* gene, int p0, int p1, int mq, int r
         if (relpos < 0) relpos = 0;
         crop_to_window(p0, p1, ops, rp0, rp1, cr);
         if (!cr.ok || cr.lead > r->slen || cr.trail > r->quallen) {
-            a->error = "a read cannot be cropped to the window (soft clips / CIGAR longer than its bases)";
+            tl_error = "a read cannot be cropped to the window (soft clips / CIGAR longer than its bases)";
             return SC_ERR_ARG;
         }
         const int cnt = r->slen - cr.lead - cr.trail;

@@ -225,9 +225,10 @@ class SamText:
                 elif op == "I":
                     j += n
                 elif op in "DN":
+                    ch = "*" if op == "D" else ("<" if rev else ">")      # mpileup: deleted base / reference skip
                     for t in range(n):
                         if a0 is None or a0 <= p <= b0:
-                            cols.setdefault(p, []).append("*" + ("$" if p == e else ""))
+                            cols.setdefault(p, []).append(ch + ("$" if p == e else ""))
                         p += 1
         return ["%s\t%d\tN\t%d\t%s\t%s" % (name, p, len(cols[p]), "".join(cols[p]), "I" * len(cols[p]))
                 for p in sorted(cols)]
@@ -300,7 +301,8 @@ def _sam_pileup_flags(self, mq, region):
                 if a <= b:
                     cover[a - lo] += 1
                     cover[b - lo + 1] -= 1
-                    dele[a - lo:b - lo + 1] = True
+                    if op == "D":                         # a reference skip prints '>' / '<': no deletion mark
+                        dele[a - lo:b - lo + 1] = True
                 p += ln
     depth = np.cumsum(cover[:n])
     out = {}

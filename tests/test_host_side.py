@@ -372,5 +372,25 @@ def test_bam_decoder_on_hand_assembled_bytes(tmp_path):
     assert (got.pos, got.cigar, got.seq, got.copies) == ([2, 9], ["3M1M2I1D2M", "2H5M4N1P3M3H"], ["ACGTAACG", "GGGGGCCC"], [1, 1])
     assert got.mates == [[-1], [-1]]                         # r1 -> "r1/1" (flag 99 has 65 set? 99 = 1+2+32+64: yes), mate "r1/2" absent
     assert aln.load_reads("", "otuB", 1, 40, 0, 0, 13, 800).n_input == 0      # flag 73 & 1804 = 8: mate unmapped is filtered by -F 1804
-    # pileup: r1 covers 3-9 (insertion marked on the base before it, 6; deleted base 7), r2 covers 10-21 (skipped 15-18 read as '*')
-    assert aln.pileup_flags(0, "otuA", 1, 50) == {p: (p == 6, p == 7 or 15 <= p <= 18) for p in range(3, 22)}
+    # pileup: r1 covers 3-9 (insertion marked on the base before it, 6; deleted base 7), r2 covers 10-21; its reference
+    # skip 15-18 prints '<' (reverse strand), which window_adjust (StrainCall.cpp:712-735) does not read as a deletion
+    assert aln.pileup_flags(0, "otuA", 1, 50) == {p: (p == 6, p == 7) for p in range(3, 22)}
+
+
+def test_reference_skip_is_coverage_not_deletion(tmp_path):
+    """CIGAR N (reference skip): mpileup prints '>' / '<' there, not '*'; window_adjust looks for '+', '-' and '*' only
+    (StrainCall.cpp:712-735), so the skipped span counts as covered and carries no deletion mark -- in the native
+    reader, in the Python mirror and in the pileup text of the stand-in alike."""
+    from rambl_amd import capi, samio
+    sam = tmp_path / "n.sam"
+    sam.write_text("@SQ\tSN:g\tLN:60\n"
+                   "a\t0\tg\t5\t30\t4M3N4M1D2M\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII\n"
+                   "b\t16\tg\t20\t30\t3M2N3M\t*\t0\t0\tACGTAC\tIIIIII\n")
+    want = {p: (False, p in (15, 16)) for p in list(range(5, 19)) + list(range(20, 28))}     # 15: "-1N" on the base before; 16: '*'
+    nat = capi.NativeAln(str(sam))
+    assert nat.pileup_flags(0, "g", 1, 60) == want
+    text = samio.SamText(str(sam))
+    assert text.pileup_flags(0, "g:1-60") == want
+    lines = text.mpileup(0, "g:1-60")
+    assert samio.flags_from_pileup_text(lines) == want
+    assert ">" in lines[4].split("\t")[4] and "<" in [ln for ln in lines if ln.split("\t")[1] == "23"][0].split("\t")[4]
