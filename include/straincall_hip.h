@@ -20,8 +20,9 @@
  *
  * Conventions: the caller owns every buffer; every function returns 0 on success
  * or a negative SC_ERR_* code and never throws; a context is bound to one HIP
- * device; sc_roi_submit may be called from one host thread at a time, the regions
- * run on `stream_count` worker threads, each with its own HIP stream.
+ * device; sc_roi_submit may be called from one host thread at a time; up to
+ * `stream_count` regions are in flight at once, as fibers on a few host threads
+ * sized from the CPU quota of the rank (sc_host_plan), not one thread per region.
  * There is no CPU fallback: if no gfx950 device is present sc_ctx_create fails.
  */
 #ifndef STRAINCALL_HIP_H
@@ -84,6 +85,15 @@ typedef struct sc_stats {
 int sc_ctx_create(int device, int stream_count, sc_ctx** ctx_out);
 void sc_ctx_destroy(sc_ctx* ctx);
 const char* sc_last_error(sc_ctx* ctx);
+/* The message of one region (sc_last_error holds the context's latest, which may be another region's when several
+ * fail side by side).  Valid until sc_roi_release. */
+const char* sc_roi_error(sc_ctx* ctx, int handle);
+/* Host threads a context with `stream_count` regions in flight starts: out[0] executor threads (they run the regions'
+ * fibers), out[1] the level server (0 or 1), out[2] threads sc_aln_open inflates BGZF members on.  `cpus` = CPUs of the
+ * host share (0: the cgroup quota / affinity mask of the process), divided by `local_world` ranks sharing it (0: the
+ * environment's LOCAL_WORLD_SIZE, as torch.distributed.run sets it) -- rambl.py's Pool(cores) (scripts/rambl.py:190-194)
+ * gives every region a process; here eight ranks on one host must fit its cores.  No device needed. */
+int sc_host_plan(int stream_count, int local_world, double cpus, int* out);
 
 /* Replaces `new PartialOrderGraph(gene_seq, reads)` + infer_strains + read_assign
  * + the sort (StrainCall.cpp:1017-1027).

@@ -47,6 +47,10 @@ def load_library():
     lib.sc_ctx_destroy.restype = None
     lib.sc_last_error.argtypes = [vp]
     lib.sc_last_error.restype = cp
+    lib.sc_roi_error.argtypes = [vp, C.c_int]
+    lib.sc_roi_error.restype = cp
+    lib.sc_host_plan.argtypes = [C.c_int, C.c_int, C.c_double, ip]
+    lib.sc_host_plan.restype = C.c_int
     lib.sc_roi_submit.argtypes = [vp, cp, C.c_int, ip, cp, ip, cp, ip, ip, ip, ip, C.c_int, C.POINTER(ScParams), ip]
     lib.sc_roi_wait.argtypes = [vp, C.c_int]
     lib.sc_roi_result.argtypes = [vp, C.c_int, C.c_char_p, C.c_long, ip, C.POINTER(C.c_double), C.c_int, ip]
@@ -80,7 +84,7 @@ def load_library():
     return lib
 
 
-EXPORTS = ["sc_ctx_create", "sc_ctx_destroy", "sc_last_error", "sc_roi_submit", "sc_roi_wait", "sc_roi_result",
+EXPORTS = ["sc_ctx_create", "sc_ctx_destroy", "sc_last_error", "sc_roi_error", "sc_host_plan", "sc_roi_submit", "sc_roi_wait", "sc_roi_result",
            "sc_roi_graph_dump", "sc_roi_trace", "sc_roi_stats", "sc_roi_release", "sc_roi_edge_support", "sc_msa_align",
            "sc_roi_thread_tables", "sc_aln_open", "sc_aln_close", "sc_aln_error", "sc_aln_records", "sc_aln_ref_stats", "sc_aln_pileup_flags",
            "sc_aln_load_reads", "sc_reads_get", "sc_reads_free", "sc_depth_scan", "sc_depth_scan_runs"]
@@ -98,6 +102,15 @@ def _pack(strings):
         n += len(s)
     off[len(strings)] = n
     return "".join(strings).encode("ascii"), off
+
+
+def host_plan(streams, local_world=0, cpus=0.0):
+    """(executor threads, level-server threads, ingest threads) a Context(streams) starts on this host share."""
+    out = (C.c_int * 3)()
+    rc = lib().sc_host_plan(streams, local_world, cpus, out)
+    if rc != SC_OK:
+        raise StrainCallError(rc)
+    return tuple(out)
 
 
 _LIB = None
@@ -304,7 +317,8 @@ class Context:
             if self.lib.sc_roi_graph_dump(self.h, handle, buf, ln.value, C.byref(ln)) == SC_OK:
                 graph = buf.raw[:ln.value].decode("ascii")
         if rc != SC_OK:
-            err = self._err(rc)
+            msg = self.lib.sc_roi_error(self.h, handle)            # this region's own message
+            err = StrainCallError(rc, msg.decode("utf-8", "replace") if msg else "")
             if release:
                 self.lib.sc_roi_release(self.h, handle)
             err.graph = graph

@@ -31,6 +31,7 @@
 
 #include "../../include/straincall_hip.h"
 #include "sc_device.hpp"
+#include "sc_fiber.hpp"
 #include "sc_graph.hpp"
 
 namespace sc {
@@ -42,6 +43,7 @@ void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node
 bool level_wants_grid(const JobDev& job, const LevelHdr& h);
 int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* Pd);
 int level_kind(const LevelHdr& h);
+int level_lds_kb(const LevelHdr& h, int K);
 int level_table_capacity();
 void launch_level_batch(hipStream_t st, int kind, const LevelBatch& b, int n);
 void launch_level_any(hipStream_t st, const LevelBatch& b, int n);
@@ -104,14 +106,14 @@ struct PinnedArena {
     void reset() { for (Chunk& c : chunks) c.used = 0; back.clear(); }
     void h2d(void* dst, const void* src, size_t n, hipStream_t st) {
         if (n == 0) return;
-        if (!on || n < 4096) { HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st)); return; }
+        if (!on) { HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st)); return; }
         void* q = take(n);
         memcpy(q, src, n);
         HIPCHK(hipMemcpyAsync(dst, q, n, hipMemcpyHostToDevice, st));
     }
     void d2h(void* dst, const void* src, size_t n, hipStream_t st) {          // complete after the stream's synchronisation + land()
         if (n == 0) return;
-        if (!on || n < 4096) { HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st)); return; }
+        if (!on) { HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st)); return; }
         void* q = take(n);
         HIPCHK(hipMemcpyAsync(q, src, n, hipMemcpyDeviceToHost, st));
         back.push_back(Back{dst, q, n});
@@ -210,19 +212,27 @@ struct Ctx {
     int device = 0;
     // page-locked staging arenas, shared: a region holds one only while it is set up, so a handful serves any number in flight
     std::mutex amu;
-    std::condition_variable acv;
     std::vector<PinnedArena*> arenas, free_arenas;
     int arena_limit = 0;              // 0: staging off (one region in flight, or SC_PINNED_STAGING=0)
     PinnedArena* lease_arena(PinnedArena* passthrough);
     void release_arena(PinnedArena* a);
     std::string last_error;
-    std::mutex mu;
-    std::condition_variable cv_job, cv_done;
+    std::mutex mu;                    // guards queue, jobs, idle, stop, last_error, job status
+    std::condition_variable cv_done;
     std::deque<std::shared_ptr<Job>> queue;
     std::map<int, std::shared_ptr<Job>> jobs;
     int next_handle = 1;
     bool stop = false;
+    // Regions in flight are fibers (sc_fiber.hpp): `workers` are the slots (stream_count of them, each with its device
+    // buffers and its host-mapped parameter / result blocks), `pool` the few host threads that run whichever of them
+    // is ready -- sized from the CPU quota of this rank, not from the number of regions in flight.
     std::vector<std::unique_ptr<Worker>> workers;
+    std::vector<Worker*> idle;                // slots without a region, parked
+    std::unique_ptr<FiberPool> pool;
+    std::atomic<int> fibers_left{0};
+    LevelParams* P_all = nullptr;             // host-mapped blocks of all slots (one allocation each)
+    LevelResult* R_all = nullptr;
+    LevelParams* Pd_all = nullptr;
     std::vector<LaunchStream> lstreams;
     std::vector<hipStream_t> setup_streams;   // uploads, graph kernels: shared round-robin by the workers
     // the level server: one thread launches every level and sees every completion stamp (serve_levels)
@@ -236,12 +246,11 @@ struct Ctx {
     void serve_levels();
     double* dU = nullptr;             // uniform stream on the device
     float* dUf = nullptr;             // fp32 copy
-    int wait_mode = 0;                // how a worker waits for its level's stamp: WAIT_*
 };
-enum { WAIT_SPIN = 0, WAIT_SLEEP = 1 };
 
-// CPUs this process may use: the cgroup quota when there is one (a GPU box hands out a share of its host)
-static double cpu_budget() {
+// CPUs this rank may use: the cgroup quota when there is one (a GPU box hands out a share of its host), divided among the
+// ranks that share the host (one process per GPU: LOCAL_WORLD_SIZE, set by torch.distributed.run and by bench.py).
+static double cpu_budget_host() {
     double n = (double)std::thread::hardware_concurrency();
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
         char quota[64] = {0};
@@ -252,21 +261,46 @@ static double cpu_budget() {
         }
         fclose(f);
     }
-    return n > 0 ? n : 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int k = CPU_COUNT(&set); if (k > 0 && k < n) n = k; }
+    return n > 1 ? n : 1;
 }
+static int local_world_size() {
+    const char* e = getenv("LOCAL_WORLD_SIZE");
+    const int k = e ? atoi(e) : 1;
+    return k > 1 ? k : 1;
+}
+}  // namespace sc
+// Host threads a context with `stream_count` regions in flight starts on a rank that shares its host with
+// `local_world - 1` others (0: read LOCAL_WORLD_SIZE), given `cpus` CPUs for the host (0: the cgroup quota / affinity
+// mask): out[0] executor threads (they run the regions' fibers), out[1] the level server, out[2] ingest threads of
+// sc_aln_open.  Pure arithmetic (no device): tests/test_stage5.py checks that 8 ranks on 16 CPUs stay within them.
+extern "C" int sc_host_plan(int stream_count, int local_world, double cpus, int* out) {
+    if (!out || stream_count < 1) return SC_ERR_ARG;
+    double n = cpus > 0 ? cpus : sc::cpu_budget_host();
+    n /= local_world > 0 ? local_world : sc::local_world_size();
+    if (n < 1) n = 1;
+    int exec = (int)n - 1;                     // one CPU for the level server
+    if (exec < 1) exec = 1;
+    if (exec > stream_count) exec = stream_count;
+    if (exec > 32) exec = 32;
+    out[0] = exec; out[1] = stream_count > 1 ? 1 : 0;
+    out[2] = (int)std::min<double>(std::max<double>(n, 1), 32);
+    return SC_OK;
+}
+namespace sc {
 
 struct Worker {
     Ctx* ctx;
-    std::thread th;
+    Fiber* fib = nullptr;
     int slot = 0;                     // worker index
     hipStream_t st = nullptr;         // a setup stream of the context (not owned), or a private one (own_stream)
     bool own_stream = false;
+    hipEvent_t sync_ev = nullptr;     // marks "everything this worker has put on `st` so far" (sync_stream)
     // hand-shake with the level server: 1 = a level is on its way / in flight, 2 = its stamp was seen, 3 = failed
     std::atomic<int> level_state{0};
     unsigned level_want = 0;          // stamp of that level
     int cur_stream = -1;              // its launch stream (server's bookkeeping)
-    std::mutex wmu;
-    std::condition_variable wcv;
     std::string level_err;
     double t_batch_launched = 0;      // diagnostics: when the level's batch was launched, and its size
     int batch_n = 0;
@@ -278,6 +312,7 @@ struct Worker {
     LevelParams* Pd = nullptr;        // device copy, only for the grid kernels of very large levels
     LevelResult* Rh = nullptr;        // host-mapped, written by the kernel, stamped last
     LevelResult* Rd = nullptr;
+    bool own_blocks = false;          // Ph / Pd / Rh are this worker's own allocations (sc_msa_align's private worker)
     unsigned seq = 0;                 // stamp of the last level launched
     DevBuf b_ent_rid, b_ent_cn, b_ent_lab_off, b_ent_lab_len, b_ent_first, b_ent_qoff, b_labels, b_mate_ptr, b_mate_idx,
         b_ll, b_has, b_isnew, b_tabA, b_tabLf, b_qcode, b_qent, b_quid, b_out_ptr, b_out_node, b_pool_ptr, b_pool_rid,
@@ -287,11 +322,13 @@ struct Worker {
                                       // for the region's set-up (Ctx::lease_arena), handed back when its copies have landed
     PinnedArena passthrough;          // on = false
     DevBuf t_ref, t_pos, t_seqoff, t_seq, t_cigoff, t_cigop, t_ciglen, t_lut, t_tabs, t_pool, t_pool2;
+    std::vector<ld> cnt_scratch;      // [MAXS][KMAX] draws per (strain, read symbol) of the level just sampled
 
     void init();
     void run();
     void process(Job& job);
     void wait_level();
+    void sync_stream();
     int msa_device(const std::vector<std::string>& seqs, std::vector<std::string>& rows);
     void thread_device(const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cig,
                        ThreadTables& T);
@@ -301,45 +338,71 @@ struct Worker {
 void Worker::init() {
     HIPCHK(hipSetDevice(ctx->device));
     if (!st) { HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
-    HIPCHK(hipHostMalloc((void**)&Ph, sizeof(LevelParams), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipEventCreateWithFlags(&sync_ev, hipEventDisableTiming));
+    if (!Ph) {
+        own_blocks = true;
+        HIPCHK(hipHostMalloc((void**)&Ph, sizeof(LevelParams), hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(hipMalloc((void**)&Pd, sizeof(LevelParams)));
+        HIPCHK(hipHostMalloc((void**)&Rh, sizeof(LevelResult), hipHostMallocMapped | hipHostMallocCoherent));
+    }
     HIPCHK(hipHostGetDevicePointer((void**)&Pm, Ph, 0));
-    HIPCHK(hipMalloc((void**)&Pd, sizeof(LevelParams)));
-    HIPCHK(hipHostMalloc((void**)&Rh, sizeof(LevelResult), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&Rd, Rh, 0));
     std::memset(Rh, 0, sizeof(LevelResult));
+    cnt_scratch.assign((size_t)MAXS * KMAX, 0);
 }
 
-// The level server.  Workers hand their next level to this thread and wait; it is the only thread that launches level
+// Everything this worker has put on its set-up stream is done.  The stream is shared with other regions, so the wait is
+// for an event recorded now, not for the stream to drain; a fiber lets the other ready regions run meanwhile.
+void Worker::sync_stream() {
+    if (!FiberPool::in_fiber() || ctx->workers.size() <= 1) { HIPCHK(hipStreamSynchronize(st)); return; }
+    HIPCHK(hipEventRecord(sync_ev, st));
+    for (;;) {
+        const hipError_t e = hipEventQuery(sync_ev);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) throw HipError(std::string("set-up stream: ") + hipGetErrorString(e));
+        FiberPool::yield();
+    }
+}
+
+// The level server.  Workers hand their next level to this thread and park; it is the only thread that launches level
 // kernels and the only one that watches the completion stamps, so a finished level is seen within a microsecond
 // however many regions are in flight, and nobody polls or contends for the launch path.
 //   * A level's kernel stores its stamp into host memory after everything else it reports (system-scope release):
-//     completion is seen without a stream synchronisation.
+//     completion is seen without a stream synchronisation; the region's fiber is made ready and an executor thread
+//     picks it up (no futex round trip per level).
 //   * Launch streams are shared by all regions.  A stream carries one batch at a time, so kernels of different
 //     regions never queue behind each other; while a stream is free, every waiting level (up to MAXB) leaves as one
 //     grid, workgroup b = region b of the batch: the kernel of their kind when they all need the same one, k_level_any
 //     (which calls the variant each item names) otherwise.  SC_ANY_KIND=0 keeps one kind per launch (measurements).
+//   * A launch the runtime rejects fails the levels of its batch at once; a stream that drains while stamps of its
+//     batch are still missing (a kernel that ended without stamping) fails them at the periodic check.
 PinnedArena* Ctx::lease_arena(PinnedArena* passthrough) {
     if (arena_limit <= 0) { passthrough->on = false; return passthrough; }
-    std::unique_lock<std::mutex> lk(amu);
     for (;;) {
-        if (!free_arenas.empty()) { PinnedArena* a = free_arenas.back(); free_arenas.pop_back(); a->reset(); return a; }
-        if ((int)arenas.size() < arena_limit) { PinnedArena* a = new PinnedArena(); arenas.push_back(a); return a; }
-        acv.wait(lk);
+        {
+            std::lock_guard<std::mutex> lk(amu);
+            if (!free_arenas.empty()) { PinnedArena* a = free_arenas.back(); free_arenas.pop_back(); a->reset(); return a; }
+            if ((int)arenas.size() < arena_limit) { PinnedArena* a = new PinnedArena(); arenas.push_back(a); return a; }
+        }
+        // every arena is with a region that is being set up: let those regions run
+        if (FiberPool::in_fiber()) FiberPool::yield(); else std::this_thread::yield();
     }
 }
 void Ctx::release_arena(PinnedArena* a) {
-    { std::lock_guard<std::mutex> lk(amu); free_arenas.push_back(a); }
-    acv.notify_one();
+    std::lock_guard<std::mutex> lk(amu);
+    free_arenas.push_back(a);
 }
 void Ctx::serve_levels() {
     (void)hipSetDevice(device);
     std::deque<LevelRequest> waiting;          // taken from `pending`, not launched yet
     std::vector<Worker*> flying;               // launched, stamp not seen yet
     std::string dead;                          // non-empty: a launch stream has failed, every level fails from now on
-    auto finish = [](Worker* w, int state, const std::string& err) {
-        { std::lock_guard<std::mutex> lk(w->wmu); w->level_err = err; w->level_state.store(state, std::memory_order_release); }
-        w->wcv.notify_one();
+    auto finish = [this](Worker* w, int state, const std::string& err) {
+        w->level_err = err;
+        w->level_state.store(state, std::memory_order_release);
+        pool->make_ready(w->fib);
     };
+    auto stamped = [](Worker* w) { return __atomic_load_n(&w->Rh->seq, __ATOMIC_ACQUIRE) == w->level_want; };
     unsigned idle_spins = 0;
     const bool any_kind = !(getenv("SC_ANY_KIND") && atoi(getenv("SC_ANY_KIND")) == 0);
     for (;;) {
@@ -354,7 +417,7 @@ void Ctx::serve_levels() {
         // completions
         for (size_t i = 0; i < flying.size();) {
             Worker* w = flying[i];
-            if (__atomic_load_n(&w->Rh->seq, __ATOMIC_ACQUIRE) == w->level_want) {
+            if (stamped(w)) {
                 lstreams[(size_t)w->cur_stream].busy--;
                 w->cur_stream = -1;
                 flying[i] = flying.back(); flying.pop_back();
@@ -383,9 +446,18 @@ void Ctx::serve_levels() {
                 it = waiting.erase(it);
             }
             hipStream_t st = lstreams[(size_t)fs].st;
+            (void)hipGetLastError();
             if (timed) for (int i = 0; i < n; i++) (void)hipEventRecord(who[i]->ev0, st);
             if (mixed) launch_level_any(st, batch, n);          // every waiting level, whatever variant it needs
             else launch_level_batch(st, kind, batch, n);
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) {
+                // the runtime did not take the launch: nothing of this batch will ever stamp
+                const std::string msg = std::string("level kernel launch: ") + hipGetErrorString(le);
+                for (int i = 0; i < n; i++) finish(who[i], 3, msg);
+                progressed = true;
+                continue;
+            }
             if (timed) for (int i = 0; i < n; i++) (void)hipEventRecord(who[i]->ev1, st);
             lstreams[(size_t)fs].busy = n;
             lstreams[(size_t)fs].unretired++;
@@ -402,11 +474,23 @@ void Ctx::serve_levels() {
         }
         __builtin_ia32_pause();
         if ((++idle_spins & 0xFFFFFu) == 0) {
-            // nothing has moved for a while: has a stream died under its batch?
-            for (auto& ls : lstreams) {
+            // nothing has moved for a while: has a stream died under its batch, or drained without every stamp of it?
+            for (size_t si = 0; si < lstreams.size(); si++) {
+                LaunchStream& ls = lstreams[si];
                 if (ls.busy == 0) continue;
                 const hipError_t e = hipStreamQuery(ls.st);
-                if (e != hipSuccess && e != hipErrorNotReady) dead = std::string("level kernel: ") + hipGetErrorString(e);
+                if (e == hipErrorNotReady) continue;
+                if (e != hipSuccess) { dead = std::string("level kernel: ") + hipGetErrorString(e); break; }
+                // the stream is empty: every kernel of the batch has ended, so a stamp that is still missing now (read
+                // again after the query) will never come
+                for (size_t i = 0; i < flying.size();) {
+                    Worker* w = flying[i];
+                    if (w->cur_stream != (int)si || stamped(w)) { ++i; continue; }
+                    ls.busy--;
+                    w->cur_stream = -1;
+                    flying[i] = flying.back(); flying.pop_back();
+                    finish(w, 3, "a level kernel ended without its completion stamp");
+                }
             }
             if (!dead.empty()) {
                 for (Worker* w : flying) { lstreams[(size_t)w->cur_stream].busy = 0; w->cur_stream = -1; finish(w, 3, dead); }
@@ -426,15 +510,14 @@ void Ctx::submit_level(const LevelRequest& rq) {
     }
     dcv.notify_one();
 }
-// Few regions in flight: spin (the server's hand-over is seen at once); more regions than this process has cores: sleep.
+// The region's fiber parks until the server has seen the level's stamp (or failed the level).  The server makes the
+// fiber ready exactly once per request, so the fiber parks exactly once per request -- also when the level is already
+// done by the time it gets here (it then comes straight back).
 void Worker::wait_level() {
-    if (ctx->wait_mode == WAIT_SPIN) {
-        while (level_state.load(std::memory_order_acquire) == 1) __builtin_ia32_pause();
-    } else {
-        std::unique_lock<std::mutex> lk(wmu);
-        wcv.wait(lk, [&] { return level_state.load(std::memory_order_acquire) != 1; });
-    }
-    if (level_state.load(std::memory_order_acquire) == 3) throw HipError(level_err);
+    FiberPool::park();
+    const int state = level_state.load(std::memory_order_acquire);
+    if (state == 3) throw HipError(level_err);
+    if (state != 2) throw HipError("a region was resumed before its level was done");
 }
 
 // a7 on the device.  Returns the number of columns.
@@ -449,8 +532,8 @@ int Worker::msa_device(const std::vector<std::string>& seqs, std::vector<std::st
     MsaDev d;
     char* dseq = (char*)m_seqs.ensure(packed.size() + 1);
     int* doff = (int*)m_off.ensure(sizeof(int) * (n + 1));
-    HIPCHK(hipMemcpyAsync(dseq, packed.data(), packed.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(doff, off.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, st));
+    stage->h2d(dseq, packed.data(), packed.size(), st);               // page-locked staging while other regions are in flight
+    stage->h2d(doff, off.data(), sizeof(int) * (n + 1), st);
     d.seqs = dseq; d.seq_off = doff; d.n = n; d.cmax = cmax;
     d.cols[0] = (char*)m_cols0.ensure((size_t)cmax * n);
     d.cols[1] = (char*)m_cols1.ensure((size_t)cmax * n);
@@ -463,8 +546,9 @@ int Worker::msa_device(const std::vector<std::string>& seqs, std::vector<std::st
     d.ncol_out = dout; d.err_out = dout + 1;
     launch_msa(st, d);
     int out[2];
-    HIPCHK(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    stage->d2h(out, dout, sizeof(out), st);
+    sync_stream();
+    stage->land();
     if (out[1] & 0xFF) {
         size_t longest = 0;
         for (auto& q : seqs) longest = std::max(longest, q.size());
@@ -475,7 +559,11 @@ int Worker::msa_device(const std::vector<std::string>& seqs, std::vector<std::st
     }
     const int ncol = out[0], cur = out[1] >> 8;
     std::vector<char> cols((size_t)ncol * n);
-    if (ncol > 0) HIPCHK(hipMemcpy(cols.data(), d.cols[cur], (size_t)ncol * n, hipMemcpyDeviceToHost));
+    if (ncol > 0) {
+        stage->d2h(cols.data(), d.cols[cur], (size_t)ncol * n, st);
+        sync_stream();
+        stage->land();
+    }
     rows.assign(n, std::string((size_t)ncol, '-'));
     for (int c = 0; c < ncol; c++)
         for (int k = 0; k < n; k++) rows[k][c] = cols[(size_t)c * n + k];
@@ -526,7 +614,7 @@ void Worker::thread_device(const std::string& G, const std::vector<AlignedRead>&
     d.cig_op = dop;
     d.cig_len = upload(*stage, t_ciglen, cig_len, st);
     uint8_t* dlut = (uint8_t*)t_lut.ensure(256);
-    HIPCHK(hipMemcpyAsync(dlut, T.lut, 256, hipMemcpyHostToDevice, st));
+    stage->h2d(dlut, T.lut, 256, st);
     d.lut = dlut;
     // tables: count | minrid | smin | emin (ncls each) | tmin (8*ncls) | off (ncls+1) | cursor (ncls) | err
     const size_t words = (size_t)ncls * 4 + (size_t)ncls * 8 + (size_t)ncls + 1 + (size_t)ncls + 1;
@@ -549,9 +637,9 @@ void Worker::thread_device(const std::string& G, const std::vector<AlignedRead>&
     stage->d2h(T.tmin.data(), d.tmin, sizeof(int) * (size_t)ncls * 8, st);
     stage->d2h(T.off.data(), d.off, sizeof(int) * ((size_t)ncls + 1), st);
     stage->d2h(T.pool.data(), pool_sorted, sizeof(int) * (size_t)std::max<long>(m_bases, 0), st);
-    HIPCHK(hipMemcpyAsync(&err, d.err, sizeof(int), hipMemcpyDeviceToHost, st));
+    stage->d2h(&err, d.err, sizeof(int), st);
     const double t_sync0 = now_ms();
-    HIPCHK(hipStreamSynchronize(st));
+    sync_stream();
     stage->land();
     if (getenv("SC_SYNC_LOG")) fprintf(stderr, "sync thread_device %.3f ms\n", now_ms() - t_sync0);
     if (err) throw ScError(SC_ERR_ARG, "a read runs outside the window or past its own bases");
@@ -672,7 +760,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     jd.quid = (int*)b_quid.ensure(sizeof(int) * (size_t)qcap);
     // the batched level kernels find the region through a pointer: the block travels once, with the uploads
     const JobDev* jd_dev = (const JobDev*)b_jobdev.ensure(sizeof(JobDev));
-    HIPCHK(hipMemcpyAsync((void*)jd_dev, &jd, sizeof jd, hipMemcpyHostToDevice, st));
+    stage->h2d((void*)jd_dev, &jd, sizeof jd, st);
 
     // ---- a16: every edge support on the device
     {
@@ -691,7 +779,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         if (!esrc.empty())
             stage->d2h(f.out_support.data(), d_sup, sizeof(int) * esrc.size(), st);
         const double t_sync0 = now_ms();
-        HIPCHK(hipStreamSynchronize(st));
+        sync_stream();
         stage->land();
         if (stage != &passthrough) ctx->release_arena(stage);      // every transfer of the set-up is done
         stage = &passthrough;
@@ -816,7 +904,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             const size_t bytes = offsetof(LevelParams, lpt) + sizeof(double) * (size_t)S * K * K;
             HIPCHK(hipMemcpyAsync(Pd, Ph, bytes, hipMemcpyHostToDevice, st));
             H.done = launch_level_grid(st, jd, H, Pd);
-            HIPCHK(hipStreamSynchronize(st));            // the level's kernel runs on another stream
+            sync_stream();                               // the level's kernel runs on another stream
         }
         H.seq = ++seq;
         level_want = H.seq;
@@ -834,10 +922,12 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         if (ctx->workers.size() == 1) {
             // a single region in flight: nobody to batch with, so the worker launches its level itself and watches the stamp
             LevelBatch batch;
-            batch.it[0] = LevelItem{jd_dev, H, level_kind(H), Pm, Rd};
+            batch.it[0] = LevelItem{jd_dev, H, level_kind(H) | (level_lds_kb(H, K) << 8), Pm, Rd};
             hipStream_t ls = ctx->lstreams[0].st;
             if (timed) HIPCHK(hipEventRecord(ev0, ls));
+            (void)hipGetLastError();
             launch_level_batch(ls, level_kind(H), batch, 1);
+            { const hipError_t le = hipGetLastError(); if (le != hipSuccess) throw HipError(std::string("level kernel launch: ") + hipGetErrorString(le)); }
             if (timed) HIPCHK(hipEventRecord(ev1, ls));
             t_batch_launched = level_log ? now_ms() : 0.0; batch_n = 1;
             // while this level runs: let the runtime retire the launches behind it (it does so only when asked, and a
@@ -853,7 +943,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 }
             }
         } else {
-            ctx->submit_level(LevelRequest{this, LevelItem{jd_dev, H, level_kind(H), Pm, Rd}, level_kind(H), timed});
+            ctx->submit_level(LevelRequest{this, LevelItem{jd_dev, H, level_kind(H) | (level_lds_kb(H, K) << 8), Pm, Rd}, level_kind(H), timed});
             wait_level();
         }
         level_launches++;
@@ -942,7 +1032,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 ld prior[MAXS], post[MAXS], a[MAXS];
                 for (int s = 0; s < S; s++) prior[s] = level_strains[last[s]].abundance;
                 run_level(MODE_SAMPLE, e0, e1, Q, n, true, level_strains, has_dups, any_multi);
-                static thread_local ld cnt[MAXS][KMAX];
+                ld (*cnt)[KMAX] = reinterpret_cast<ld (*)[KMAX]>(cnt_scratch.data());     // (not thread_local: the fiber changes threads)
                 for (int s = 0; s < S; s++) for (int b = 0; b < KMAX; b++) cnt[s][b] = 0;
                 if (S == 1 || n <= 0) {
                     // a single weight consumes no random numbers (libstdc++ discrete_distribution)
@@ -1164,26 +1254,27 @@ void Worker::process(Job& job) {
     job.stats.cluster_ms = now_ms() - t1;
 }
 
+// The body of a slot's fiber: takes regions off the context's queue until the context stops; parks in `idle` while there
+// is none (sc_roi_submit makes one idle slot ready per region it queues).
 void Worker::run() {
-    try { init(); } catch (const std::exception& ex) {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        ctx->last_error = ex.what();
-    }
     for (;;) {
         std::shared_ptr<Job> job;
+        bool parked = false;
         {
-            std::unique_lock<std::mutex> lk(ctx->mu);
-            ctx->cv_job.wait(lk, [&] { return ctx->stop || !ctx->queue.empty(); });
-            if (ctx->stop && ctx->queue.empty()) break;
-            job = ctx->queue.front(); ctx->queue.pop_front();
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            if (!ctx->queue.empty()) { job = ctx->queue.front(); ctx->queue.pop_front(); }
+            else if (ctx->stop) break;
+            else { ctx->idle.push_back(this); parked = true; }
         }
+        if (parked) { FiberPool::park(); continue; }
         try {
-            if (!st) throw HipError("worker stream was not created");
+            if (!st || !Ph) throw HipError("the slot's stream or host-mapped blocks were not created");
             process(*job);
             job->rc = SC_OK;
         } catch (const ScError& ex) { job->rc = ex.code; job->err = ex.what(); }
         catch (const HipError& ex) { job->rc = SC_ERR_HIP; job->err = ex.what(); }
         catch (const std::exception& ex) { job->rc = SC_ERR_INTERNAL; job->err = ex.what(); }
+        catch (...) { job->rc = SC_ERR_INTERNAL; job->err = "unknown exception"; }
         {
             std::lock_guard<std::mutex> lk(ctx->mu);
             job->status = 1;
@@ -1191,6 +1282,7 @@ void Worker::run() {
         }
         ctx->cv_done.notify_all();
     }
+    ctx->fibers_left.fetch_sub(1, std::memory_order_release);
 }
 
 }  // namespace sc
@@ -1229,7 +1321,7 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         return SC_ERR_HIP;
     }
     if (stream_count < 1) stream_count = 1;
-    if (stream_count > 256) stream_count = 256;
+    if (stream_count > 512) stream_count = 512;
     {
         const char* e = getenv("SC_LAUNCH_STREAMS");
         int nl = e ? atoi(e) : 11;
@@ -1243,27 +1335,49 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         for (auto& ss : ctx->setup_streams) ok = ok && hipStreamCreateWithFlags(&ss, hipStreamNonBlocking) == hipSuccess;
         if (!ok) { sc_ctx_destroy(h); return SC_ERR_HIP; }
     }
+    int plan[3] = {1, 0, 1};
+    (void)sc_host_plan(stream_count, 0, 0.0, plan);
+    if (const char* e = getenv("SC_EXEC_THREADS")) { const int k = atoi(e); if (k >= 1) plan[0] = std::min(k, stream_count); }
     {
-        // spinning workers see their level's stamp at once, but only while every one of them has a core
-        const char* e = getenv("SC_WAIT");
-        if (e && !std::strcmp(e, "spin")) ctx->wait_mode = WAIT_SPIN;
-        else if (e && !std::strcmp(e, "sleep")) ctx->wait_mode = WAIT_SLEEP;
-        else ctx->wait_mode = ((double)stream_count + 2 <= 0.6 * cpu_budget()) ? WAIT_SPIN : WAIT_SLEEP;
         // page-locked staging of the regions' transfers: only worth it while other regions are in flight (it is their queues
-        // that a pageable copy suspends); as many arenas as regions can be set up at once on this process's cores
+        // that a pageable copy suspends); as many arenas as regions can be set up at once on this rank's executor threads
         const char* ps = getenv("SC_PINNED_STAGING");
         const bool want = ps ? atoi(ps) != 0 : stream_count > 1;
-        ctx->arena_limit = want ? (int)std::min<double>(std::max(cpu_budget(), 2.0), 32.0) : 0;
+        ctx->arena_limit = want ? std::max(plan[0] + 1, 2) : 0;
     }
-    for (int i = 0; i < stream_count; i++) {
-        auto w = std::make_unique<Worker>();
-        w->ctx = ctx;
-        w->slot = i;
-        w->st = ctx->setup_streams[(size_t)i % ctx->setup_streams.size()];
-        ctx->workers.push_back(std::move(w));
+    // the slots' host-mapped parameter / result blocks: one allocation each for all slots
+    const size_t ns = (size_t)stream_count;
+    if (hipHostMalloc((void**)&ctx->P_all, ns * sizeof(LevelParams), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->R_all, ns * sizeof(LevelResult), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipMalloc((void**)&ctx->Pd_all, ns * sizeof(LevelParams)) != hipSuccess) {
+        sc_ctx_destroy(h);
+        return SC_ERR_HIP;
     }
-    ctx->server = std::thread([ctx] { ctx->serve_levels(); });
-    for (auto& w : ctx->workers) w->th = std::thread([p = w.get()] { p->run(); });
+    try {
+        for (int i = 0; i < stream_count; i++) {
+            auto w = std::make_unique<Worker>();
+            w->ctx = ctx;
+            w->slot = i;
+            w->st = ctx->setup_streams[(size_t)i % ctx->setup_streams.size()];
+            w->Ph = ctx->P_all + i; w->Rh = ctx->R_all + i; w->Pd = ctx->Pd_all + i;
+            ctx->workers.push_back(std::move(w));
+        }
+        for (auto& w : ctx->workers) w->init();
+    } catch (const std::exception& ex) {
+        ctx->last_error = ex.what();
+        sc_ctx_destroy(h);
+        return SC_ERR_HIP;
+    }
+    const int dev = device;
+    ctx->pool.reset(new FiberPool(plan[0], [dev] { (void)hipSetDevice(dev); }));
+    if (stream_count > 1) ctx->server = std::thread([ctx] { ctx->serve_levels(); });
+    ctx->fibers_left.store(stream_count, std::memory_order_release);
+    for (auto& w : ctx->workers) {
+        Worker* p = w.get();
+        p->fib = ctx->pool->create([p] { p->run(); });
+        if (!p->fib) { ctx->last_error = "cannot map a fiber stack"; ctx->fibers_left.fetch_sub(1); continue; }
+        ctx->pool->make_ready(p->fib);
+    }
     *out = h;
     return SC_OK;
 }
@@ -1271,21 +1385,27 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
 void sc_ctx_destroy(sc_ctx* h) {
     if (!h) return;
     Ctx* ctx = &h->c;
-    { std::lock_guard<std::mutex> lk(ctx->mu); ctx->stop = true; }
-    ctx->cv_job.notify_all();
-    for (auto& w : ctx->workers) if (w->th.joinable()) w->th.join();
+    if (ctx->pool) {
+        std::vector<Worker*> wake;
+        { std::lock_guard<std::mutex> lk(ctx->mu); ctx->stop = true; wake.swap(ctx->idle); }
+        for (Worker* w : wake) ctx->pool->make_ready(w->fib);
+        // regions still queued or in flight are finished first (as the worker threads of earlier versions did)
+        while (ctx->fibers_left.load(std::memory_order_acquire) > 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
     { std::lock_guard<std::mutex> lk(ctx->dmu); ctx->server_stop = true; }
     ctx->dcv.notify_all();
     if (ctx->server.joinable()) ctx->server.join();
+    if (ctx->pool) ctx->pool->shutdown();
     (void)hipSetDevice(ctx->device);
     for (auto& w : ctx->workers) {
-        if (w->Ph) (void)hipHostFree(w->Ph);
-        if (w->Pd) (void)hipFree(w->Pd);
-        if (w->Rh) (void)hipHostFree(w->Rh);
         for (hipEvent_t e : w->ev_pool) (void)hipEventDestroy(e);
+        if (w->sync_ev) (void)hipEventDestroy(w->sync_ev);
         if (w->st && w->own_stream) (void)hipStreamDestroy(w->st);
     }
     ctx->workers.clear();
+    if (ctx->P_all) (void)hipHostFree(ctx->P_all);
+    if (ctx->R_all) (void)hipHostFree(ctx->R_all);
+    if (ctx->Pd_all) (void)hipFree(ctx->Pd_all);
     for (auto& ls : ctx->lstreams) if (ls.st) (void)hipStreamDestroy(ls.st);
     for (auto& ss : ctx->setup_streams) if (ss) (void)hipStreamDestroy(ss);
 
@@ -1302,6 +1422,13 @@ const char* sc_last_error(sc_ctx* h) {
     static thread_local std::string copy;
     copy = h->c.last_error;
     return copy.c_str();
+}
+
+const char* sc_roi_error(sc_ctx* h, int handle) {
+    if (!h) return "";
+    std::lock_guard<std::mutex> lk(h->c.mu);
+    auto it = h->c.jobs.find(handle);
+    return (it == h->c.jobs.end() || it->second->status != 1) ? "" : it->second->err.c_str();
 }
 
 int sc_roi_submit(sc_ctx* h, const char* ref_bases, int ref_len, const int* read_pos, const char* cigar_text,
@@ -1335,14 +1462,16 @@ int sc_roi_submit(sc_ctx* h, const char* ref_bases, int ref_len, const int* read
     for (int v : job->mate_idx) if (v < -1 || v >= n_reads) return SC_ERR_ARG;
     job->params = *params;
     Ctx* ctx = &h->c;
+    Worker* wake = nullptr;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         job->handle = ctx->next_handle++;
         ctx->jobs[job->handle] = job;
         ctx->queue.push_back(job);
         *handle_out = job->handle;
+        if (!ctx->idle.empty()) { wake = ctx->idle.back(); ctx->idle.pop_back(); }
     }
-    ctx->cv_job.notify_one();
+    if (wake) ctx->pool->make_ready(wake->fib);
     return SC_OK;
 }
 
@@ -1454,6 +1583,8 @@ int sc_msa_align(sc_ctx* h, const char* seq_text, const int* seq_off, int n, cha
         Worker w;
         w.ctx = ctx;
         w.init();
+        w.stage = &w.passthrough;
+        w.passthrough.on = false;
         std::vector<std::string> seqs((size_t)n), rows;
         for (int i = 0; i < n; i++) seqs[i].assign(seq_text + seq_off[i], (size_t)(seq_off[i + 1] - seq_off[i]));
         int ncol;
@@ -1464,6 +1595,7 @@ int sc_msa_align(sc_ctx* h, const char* seq_text, const int* seq_off, int n, cha
         if (!rows_out || (long)n * (ncol + 1) > cap) rc = SC_ERR_CAPACITY;
         else for (int i = 0; i < n; i++) { std::memcpy(rows_out + (long)i * (ncol + 1), rows[i].data(), (size_t)ncol); rows_out[(long)i * (ncol + 1) + ncol] = 0; }
         (void)hipHostFree(w.Ph); (void)hipFree(w.Pd); (void)hipHostFree(w.Rh);
+        (void)hipEventDestroy(w.sync_ev);
         (void)hipStreamDestroy(w.st);
         return rc;
     } catch (const ScError& ex) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->last_error = ex.what(); return ex.code; }

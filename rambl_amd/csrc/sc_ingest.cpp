@@ -161,6 +161,7 @@ int inflate_threads() {
     }
     long n = (long)std::thread::hardware_concurrency();
     if (quota > 0 && quota < n) n = quota;
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const long k = atol(e); if (k > 1) n = std::max<long>(n / k, 1); }     // ranks sharing the host
     if (const char* e = getenv("SC_INGEST_THREADS")) n = atol(e);
     return (int)std::min<long>(std::max<long>(n, 1), 32);
 }

@@ -1004,7 +1004,7 @@ __device__ __noinline__ void level_plain_call(KItem* it) {
 }
 __global__ __launch_bounds__(CHAIN_THREADS) void k_level_any(LevelBatch batch) {
     KItem* it = (KItem*)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.x;      // batch is the only argument
-    const int kind = it->kind;
+    const int kind = it->kind & 0xFF;                                             // (the upper bits carry the item's LDS need)
     if (kind == 0) { level_plain_call(it); return; }
     const bool wl = (kind - 1) & 1;
 #define SC_ANY(NB) case NB: if (wl) level_sample_call<NB, true>(it); else level_sample_call<NB, false>(it); break;
@@ -1398,22 +1398,50 @@ int level_kind(const LevelHdr& h) {
     nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
     return 1 + 2 * (nb - 1) + (wl ? 1 : 0);
 }
-// every item carries its kind (LevelItem::kind)
+// LDS a level needs, in KB: the per-strain scalars, then whichever is larger of the strains' log tables (S * K * K
+// doubles, staged for the update; the soft update's histogram has the same shape) and the sampler's uniforms + weight
+// rows.  A launch asks for the largest need among its items instead of the whole CU's LDS, so that two (small sampler
+// levels) to four (levels without sampler) workgroups share a CU once more levels are in flight than the GPU has CUs.
+int level_lds_kb(const LevelHdr& h, int K) {
+    const int kind = level_kind(h);
+    const long S = h.S, Rn = h.e1 - h.e0;
+    long big = 0;
+    if ((h.do_update && Rn > 0) || h.mode == MODE_HARD) big = (long)sizeof(double) * S * K * K;
+    if (kind != 0) {
+        long rows = (long)UWIN * 4;
+        if ((kind - 1) & 1) rows += ((long)h.Q * chain_w_stride(h.S) + 16) * 4;
+        if (rows > big) big = rows;
+    }
+    long need = LDS_SMALL + big + 64;
+    if (need > LDS_TOTAL) need = LDS_TOTAL;
+    return (int)((need + 1023) / 1024);
+}
+static size_t batch_lds(const LevelBatch& b, int n) {
+    static const bool exact = !(getenv("SC_LDS_EXACT") && atoi(getenv("SC_LDS_EXACT")) == 0);
+    if (!exact) return LDS_TOTAL;
+    int kb = 0;
+    for (int i = 0; i < n; i++) { const int k = (b.it[i].kind >> 8) & 0xFFFF; kb = k > kb ? k : kb; }
+    size_t bytes = (size_t)kb * 1024;
+    if (kb == 0 || bytes > (size_t)LDS_TOTAL) bytes = LDS_TOTAL;
+    return bytes;
+}
+// every item carries its kind (LevelItem::kind, low byte) and its LDS need in KB (the bits above)
 void launch_level_any(hipStream_t st, const LevelBatch& b, int n) {
-    hipLaunchKernelGGL(k_level_any, dim3(n), dim3(CHAIN_THREADS), CHAIN_LDS, st, b);
+    hipLaunchKernelGGL(k_level_any, dim3(n), dim3(CHAIN_THREADS), batch_lds(b, n), st, b);
 }
 void launch_level_batch(hipStream_t st, int kind, const LevelBatch& b, int n) {
+    const size_t lds = batch_lds(b, n);
     if (kind == 0) {
-        hipLaunchKernelGGL(k_level, dim3(n), dim3(512), LEVEL_LDS, st, b);
+        hipLaunchKernelGGL(k_level, dim3(n), dim3(512), lds, st, b);
         return;
     }
     const bool wl = (kind - 1) & 1;
-#define SC_SAMPLE(NB) case NB: if (wl) hipLaunchKernelGGL((k_level_sample<NB, true>), dim3(n), dim3(CHAIN_THREADS), CHAIN_LDS, st, b); \
-                               else hipLaunchKernelGGL((k_level_sample<NB, false>), dim3(n), dim3(CHAIN_THREADS), CHAIN_LDS, st, b); break;
+#define SC_SAMPLE(NB) case NB: if (wl) hipLaunchKernelGGL((k_level_sample<NB, true>), dim3(n), dim3(CHAIN_THREADS), lds, st, b); \
+                               else hipLaunchKernelGGL((k_level_sample<NB, false>), dim3(n), dim3(CHAIN_THREADS), lds, st, b); break;
     switch ((kind - 1) / 2 + 1) {
         SC_SAMPLE(1) SC_SAMPLE(2) SC_SAMPLE(3) SC_SAMPLE(4) SC_SAMPLE(5) SC_SAMPLE(6) SC_SAMPLE(7)
-        default: if (wl) hipLaunchKernelGGL((k_level_sample<8, true>), dim3(n), dim3(CHAIN_THREADS), CHAIN_LDS, st, b);
-                 else hipLaunchKernelGGL((k_level_sample<8, false>), dim3(n), dim3(CHAIN_THREADS), CHAIN_LDS, st, b);
+        default: if (wl) hipLaunchKernelGGL((k_level_sample<8, true>), dim3(n), dim3(CHAIN_THREADS), lds, st, b);
+                 else hipLaunchKernelGGL((k_level_sample<8, false>), dim3(n), dim3(CHAIN_THREADS), lds, st, b);
     }
 #undef SC_SAMPLE
 }

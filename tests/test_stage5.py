@@ -111,3 +111,38 @@ def test_failing_region_does_not_take_the_others_down(tmp_path, capsys):
     assert [i for i, _ in errors] == [1, 2]
     err = capsys.readouterr().err
     assert "bare:1-300" in err and "deep" in err and "SC_ERR_UNSUPPORTED" in err
+
+
+def test_fiber_pool_runs_regions_on_a_few_threads(tmp_path):
+    """rambl_amd/csrc/sc_fiber.hpp on the CPU: 512 regions-as-fibers on 4 executor threads walk 300 levels each (park
+    per level, a server thread makes them ready); never more than 4 run at once and the process never has more than
+    4 + 2 threads -- the structure that replaces the thread per region in flight."""
+    import json
+    exe = str(tmp_path / "fiber_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "native", "fiber_check.cpp")])
+    for r, t, lv in ((512, 4, 300), (48, 8, 1500), (3, 1, 200)):
+        rec = json.loads(subprocess.run([exe, str(r), str(t), str(lv)], stdout=subprocess.PIPE, check=True, timeout=300).stdout)
+        assert rec["ok"] and rec["finished"] == r and rec["max_running"] <= t and rec["max_os_threads"] <= t + 2, rec
+
+
+def test_eight_ranks_fit_sixteen_cpus():
+    """Eight ranks on one host (one per GPU, LOCAL_WORLD_SIZE = 8) with 128-512 regions in flight each: the host
+    threads their contexts start (executors + level server) stay within the host's CPUs, whatever the number of
+    regions in flight; rambl.py's Pool(cores) sized itself to the cores the same way (scripts/rambl.py:190-194)."""
+    from rambl_amd import capi
+    for streams in (1, 16, 128, 512):
+        for cpus, world in ((16, 8), (16, 1), (256, 8), (2, 8)):
+            ex, srv, ing = capi.host_plan(streams, world, float(cpus))
+            share = max(cpus / world, 1)
+            assert 1 <= ex <= min(streams, 32) and srv == (1 if streams > 1 else 0) and 1 <= ing <= 32
+            assert ex + srv <= max(share, 2) and ing <= max(share, 1), (streams, cpus, world, ex, srv, ing)
+            if world == 8:
+                assert 8 * (ex + srv) <= max(cpus, 16)
+    # the environment's LOCAL_WORLD_SIZE is what a rank under torch.distributed.run sees
+    code = ("import os, sys; sys.path.insert(0, %r); from rambl_amd import capi; "
+            "print(capi.host_plan(256, 0, 16.0))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LOCAL_WORLD_SIZE="8"), stdout=subprocess.PIPE, check=True)
+    assert out.stdout.decode().strip() == "(1, 1, 2)"
+    out = subprocess.run([sys.executable, "-c", code], env={k: v for k, v in os.environ.items() if k != "LOCAL_WORLD_SIZE"},
+                         stdout=subprocess.PIPE, check=True)
+    assert out.stdout.decode().strip() == "(15, 1, 16)"

@@ -53,7 +53,8 @@ def main():
     for r in rs:
         ctx = capi.Context(0, r)
         params = capi.default_params(0.01, 0.02, 0.02)
-        stage5.run_regions(ctx, prep[:r] if os.environ.get("SC_PROBE_WARM_ALL") else prep[:min(r, 4)], r, params)        # warm
+        # warm every slot (device buffers are allocated on a slot's first region: SC_PROBE_WARM_ALL=0 leaves that in the clock)
+        stage5.run_regions(ctx, prep[:min(r, 4)] if os.environ.get("SC_PROBE_WARM_ALL") == "0" else prep[:r], r, params)
         if os.environ.get("SC_PROBE_START"):
             while time.time() < float(os.environ["SC_PROBE_START"]):
                 time.sleep(0.0005)
