@@ -47,6 +47,7 @@ int level_lds_kb(const LevelHdr& h, int K);
 int level_table_capacity();
 void launch_level_batch(hipStream_t st, int kind, const LevelBatch& b, int n);
 void launch_level_any(hipStream_t st, const LevelBatch& b, int n);
+void launch_resident(hipStream_t st, const ResidentArgs& a, int slots);
 void launch_msa(hipStream_t st, const MsaDev& d);
 void launch_thread(hipStream_t st, const ThreadDev& d, int* pool_sorted);
 int init_kernels();
@@ -208,6 +209,8 @@ struct LevelRequest { Worker* w; LevelItem item; int kind; bool timed; };
 // batch whose stamp has not been seen yet), so kernels of different regions never queue behind each other: a level
 // that finds every stream busy waits in `pending` and leaves with the next batch of its kind.
 struct LaunchStream { hipStream_t st = nullptr; int busy = 0; int unretired = 0; };
+enum { GEN_STOPPED = 0, GEN_RUNNING = 1, GEN_STOPPING = 2 };
+constexpr int KIND_POSTED = -1;        // LevelRequest::kind of a level already in its slot's mailbox: the server only watches its stamp
 struct Ctx {
     int device = 0;
     // page-locked staging arenas, shared: a region holds one only while it is set up, so a handful serves any number in flight
@@ -230,6 +233,12 @@ struct Ctx {
     std::vector<Worker*> idle;                // slots without a region, parked
     std::unique_ptr<FiberPool> pool;
     std::atomic<int> fibers_left{0};
+    // Regions being set up (graph construction: tens of milliseconds of one CPU each) at any one time: a part of the
+    // executor threads only, so that the others stay free for the continuations of the regions in flight.
+    std::atomic<int> setups{0};
+    int setup_limit = 1;
+    void setup_enter();
+    void setup_leave() { setups.fetch_sub(1, std::memory_order_release); }
     LevelParams* P_all = nullptr;             // host-mapped blocks of all slots (one allocation each)
     LevelResult* R_all = nullptr;
     LevelParams* Pd_all = nullptr;
@@ -246,6 +255,24 @@ struct Ctx {
     void serve_levels();
     double* dU = nullptr;             // uniform stream on the device
     float* dUf = nullptr;             // fp32 copy
+    // Resident level workers (k_level_resident): while regions are in flight one workgroup per slot stays on its CU and
+    // takes the slot's levels from a mailbox in host-mapped memory; no launch per level.  A "generation" of the grid lives
+    // from the first level posted after an idle period until no region is in flight any more (so that a device
+    // synchronisation by the caller never waits on it), or until the context goes.
+    bool resident = false;
+    int res_slots = 0;
+    Mailbox* mail_h = nullptr; Mailbox* mail_d = nullptr;
+    ResidentCtl* ctl_h = nullptr; ResidentCtl* ctl_d = nullptr;
+    hipStream_t rstream = nullptr;
+    std::mutex gen_mu;
+    int gen_state = 0;                // GEN_*
+    std::atomic<int> regions_active{0};
+    long generations = 0;
+    std::thread heart;                // keeps ResidentCtl::heartbeat moving while the context lives
+    std::atomic<bool> heart_stop{false};
+    void resident_ensure(Worker* w);
+    void resident_idle();
+    void resident_shutdown();
 };
 
 // CPUs this rank may use: the cgroup quota when there is one (a GPU box hands out a share of its host), divided among the
@@ -322,6 +349,7 @@ struct Worker {
                                       // for the region's set-up (Ctx::lease_arena), handed back when its copies have landed
     PinnedArena passthrough;          // on = false
     DevBuf t_ref, t_pos, t_seqoff, t_seq, t_cigoff, t_cigop, t_ciglen, t_lut, t_tabs, t_pool, t_pool2;
+    bool setup_held = false;          // this region holds one of the context's set-up places
     std::vector<ld> cnt_scratch;      // [MAXS][KMAX] draws per (strain, read symbol) of the level just sampled
 
     void init();
@@ -410,7 +438,11 @@ void Ctx::serve_levels() {
             std::unique_lock<std::mutex> lk(dmu);
             if (waiting.empty() && flying.empty()) dcv.wait(lk, [&] { return server_stop || !pending.empty(); });
             if (server_stop) break;
-            while (!pending.empty()) { waiting.push_back(pending.front()); pending.pop_front(); }
+            while (!pending.empty()) {
+                if (pending.front().kind == KIND_POSTED) { pending.front().w->cur_stream = -1; flying.push_back(pending.front().w); }
+                else waiting.push_back(pending.front());
+                pending.pop_front();
+            }
             n_pending.store(0, std::memory_order_release);
         }
         bool progressed = false;
@@ -418,7 +450,7 @@ void Ctx::serve_levels() {
         for (size_t i = 0; i < flying.size();) {
             Worker* w = flying[i];
             if (stamped(w)) {
-                lstreams[(size_t)w->cur_stream].busy--;
+                if (w->cur_stream >= 0) lstreams[(size_t)w->cur_stream].busy--;
                 w->cur_stream = -1;
                 flying[i] = flying.back(); flying.pop_back();
                 finish(w, 2, "");
@@ -492,14 +524,86 @@ void Ctx::serve_levels() {
                     finish(w, 3, "a level kernel ended without its completion stamp");
                 }
             }
+            // a resident workgroup that has left (heartbeat limit, or a fault that ended the grid) will not stamp either
+            if (resident)
+                for (size_t i = 0; i < flying.size();) {
+                    Worker* w = flying[i];
+                    if (w->cur_stream >= 0 || __atomic_load_n(&mail_h[w->slot].state, __ATOMIC_ACQUIRE) != 2u || stamped(w)) { ++i; continue; }
+                    flying[i] = flying.back(); flying.pop_back();
+                    finish(w, 3, "the slot's resident level worker has left before the level was done");
+                }
             if (!dead.empty()) {
-                for (Worker* w : flying) { lstreams[(size_t)w->cur_stream].busy = 0; w->cur_stream = -1; finish(w, 3, dead); }
+                for (Worker* w : flying) { if (w->cur_stream >= 0) lstreams[(size_t)w->cur_stream].busy = 0; w->cur_stream = -1; finish(w, 3, dead); }
                 flying.clear();
             }
         }
     }
     for (Worker* w : flying) finish(w, 3, "context destroyed");
     for (auto& rq : waiting) finish(rq.w, 3, "context destroyed");
+}
+void Ctx::setup_enter() {
+    for (;;) {
+        int n = setups.load(std::memory_order_acquire);
+        if (n < setup_limit && setups.compare_exchange_weak(n, n + 1, std::memory_order_acq_rel)) return;
+        if (FiberPool::in_fiber()) FiberPool::yield(); else std::this_thread::yield();
+    }
+}
+// A level is about to be posted to slot w->slot: make sure a generation of the resident grid is there to take it.
+void Ctx::resident_ensure(Worker* w) {
+    for (;;) {
+        {
+            std::lock_guard<std::mutex> lk(gen_mu);
+            if (gen_state == GEN_RUNNING) {
+                if (__atomic_load_n(&mail_h[w->slot].state, __ATOMIC_ACQUIRE) != 2u) return;
+                // the slot's workgroup has left although regions are in flight (the heartbeat limit): end this generation
+                __atomic_store_n(&ctl_h->stop, 1u, __ATOMIC_RELEASE);
+                gen_state = GEN_STOPPING;
+            }
+            if (gen_state == GEN_STOPPING) {
+                const hipError_t e = hipStreamQuery(rstream);
+                if (e == hipSuccess) gen_state = GEN_STOPPED;
+                else if (e != hipErrorNotReady) throw HipError(std::string("resident level workers: ") + hipGetErrorString(e));
+            }
+            if (gen_state == GEN_STOPPED) {
+                __atomic_store_n(&ctl_h->stop, 0u, __ATOMIC_RELEASE);
+                // a workgroup starts from the last stamp its slot has completed: what is in the mailbox beyond that is new
+                for (int i = 0; i < res_slots; i++) { mail_h[i].ack = __atomic_load_n(&workers[(size_t)i]->Rh->seq, __ATOMIC_ACQUIRE); mail_h[i].state = 0; }
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                ResidentArgs ra{mail_d, ctl_d, 300000000ull};                 // 3 s of 100 MHz ticks without a heartbeat
+                (void)hipGetLastError();
+                launch_resident(rstream, ra, res_slots);
+                const hipError_t le = hipGetLastError();
+                if (le != hipSuccess) throw HipError(std::string("resident level workers, launch: ") + hipGetErrorString(le));
+                gen_state = GEN_RUNNING;
+                generations++;
+                return;
+            }
+        }
+        if (FiberPool::in_fiber() && workers.size() > 1) FiberPool::yield(); else std::this_thread::yield();
+    }
+}
+// No region is in flight any more: the generation ends, so that nothing of this context stays on the GPU while the
+// caller does something else with it (a device synchronisation would wait for the grid).
+void Ctx::resident_idle() {
+    std::lock_guard<std::mutex> lk(gen_mu);
+    if (gen_state == GEN_RUNNING && regions_active.load(std::memory_order_acquire) == 0) {
+        __atomic_store_n(&ctl_h->stop, 1u, __ATOMIC_RELEASE);
+        gen_state = GEN_STOPPING;
+    }
+}
+void Ctx::resident_shutdown() {
+    if (!resident) return;
+    {
+        std::lock_guard<std::mutex> lk(gen_mu);
+        if (ctl_h) __atomic_store_n(&ctl_h->stop, 1u, __ATOMIC_RELEASE);
+        if (gen_state == GEN_RUNNING) gen_state = GEN_STOPPING;
+    }
+    if (rstream) {
+        // the grid leaves within a few naps of its pollers; bounded, so that a workgroup that does not leave cannot hold the host
+        const double t0 = now_ms();
+        while (hipStreamQuery(rstream) == hipErrorNotReady && now_ms() - t0 < 10000.0) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    gen_state = GEN_STOPPED;
 }
 void Ctx::submit_level(const LevelRequest& rq) {
     rq.w->level_state.store(1, std::memory_order_release);
@@ -787,7 +891,8 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         job.edge_support = f.out_support;
     }
 
-    // ---- level walk
+    // ---- level walk: from here on the region's host work is a few microseconds per level
+    if (setup_held) { ctx->setup_leave(); setup_held = false; }
     std::vector<HStrain> level_strains, sub_strains;
     std::vector<Model> models;                                           // pool; free entries in free_models
     std::vector<int> free_models;
@@ -898,7 +1003,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             for (int a = 0; a < K; a++) std::memcpy(dst + a * K, hm.lpc + a * KMAX, sizeof(double) * (size_t)K);
         }
         const bool chain = (mode == MODE_SAMPLE) && S > 1 && n_sweeps > 0;
-        const bool timed = chain && pa.want_timing;
+        const bool timed = chain && pa.want_timing && !ctx->resident;      // (no launch to bracket with events when the workers are resident)
         if (level_wants_grid(jd, H)) {
             // a very large level: row copies / the single-symbol update on a grid, from a device copy of the parameters
             const size_t bytes = offsetof(LevelParams, lpt) + sizeof(double) * (size_t)S * K * K;
@@ -919,7 +1024,26 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             ev_used += 2;
         }
         const double t_launched = level_log ? now_ms() : 0.0;
-        if (ctx->workers.size() == 1) {
+        if (ctx->resident) {
+            // the slot's resident workgroup takes the level from its mailbox: the item, then its stamp (release)
+            ctx->resident_ensure(this);
+            Mailbox& mb = ctx->mail_h[slot];
+            mb.item = LevelItem{jd_dev, H, level_kind(H) | (level_lds_kb(H, K) << 8), Pm, Rd};
+            __atomic_store_n(&mb.seq, H.seq, __ATOMIC_RELEASE);
+            t_batch_launched = level_log ? now_ms() : 0.0; batch_n = 1;
+            if (ctx->workers.size() == 1) {
+                unsigned spins = 0;
+                while (__atomic_load_n(&Rh->seq, __ATOMIC_ACQUIRE) != H.seq) {
+                    __builtin_ia32_pause();
+                    if ((++spins & 0xFFFFFu) == 0 && __atomic_load_n(&mb.state, __ATOMIC_ACQUIRE) == 2u &&
+                        __atomic_load_n(&Rh->seq, __ATOMIC_ACQUIRE) != H.seq)
+                        throw HipError("the resident level worker has left before the level was done");
+                }
+            } else {
+                ctx->submit_level(LevelRequest{this, LevelItem{}, KIND_POSTED, false});
+                wait_level();
+            }
+        } else if (ctx->workers.size() == 1) {
             // a single region in flight: nobody to batch with, so the worker launches its level itself and watches the stamp
             LevelBatch batch;
             batch.it[0] = LevelItem{jd_dev, H, level_kind(H) | (level_lds_kb(H, K) << 8), Pm, Rd};
@@ -1227,6 +1351,12 @@ void Worker::process(Job& job) {
         Worker* w;
         ~Lease() { if (w->stage && w->stage != &w->passthrough) w->ctx->release_arena(w->stage); w->stage = nullptr; }
     } lease{this};
+    struct Setup {                     // one of the context's set-up places, held until the level walk starts (cluster())
+        Worker* w;
+        ~Setup() { if (w->setup_held) { w->ctx->setup_leave(); w->setup_held = false; } }
+    } setup{this};
+    ctx->setup_enter();
+    setup_held = true;
     stage = ctx->lease_arena(&passthrough);
     MsaFn msa = [this](const std::vector<std::string>& seqs, std::vector<std::string>& rows) { return msa_device(seqs, rows); };
     ThreadFn thr = [this, &job](const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cg,
@@ -1275,6 +1405,9 @@ void Worker::run() {
         catch (const HipError& ex) { job->rc = SC_ERR_HIP; job->err = ex.what(); }
         catch (const std::exception& ex) { job->rc = SC_ERR_INTERNAL; job->err = ex.what(); }
         catch (...) { job->rc = SC_ERR_INTERNAL; job->err = "unknown exception"; }
+        // the last region in flight takes the resident grid with it -- before the caller learns that the region is done,
+        // so that whoever waits for the region and then synchronises the device finds the grid on its way out
+        if (ctx->regions_active.fetch_sub(1, std::memory_order_acq_rel) == 1 && ctx->resident) ctx->resident_idle();
         {
             std::lock_guard<std::mutex> lk(ctx->mu);
             job->status = 1;
@@ -1323,6 +1456,17 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
     if (stream_count < 1) stream_count = 1;
     if (stream_count > 512) stream_count = 512;
     {
+        // resident level workers: one workgroup per slot holds a CU (and all of its LDS) while regions are in flight, so the
+        // slots stop short of the 256 CUs -- the set-up kernels of the regions (read threading, MSA, edge support) need CUs too
+        const char* e = getenv("SC_RESIDENT");
+        ctx->resident = e ? atoi(e) != 0 : false;
+        const char* rs = getenv("SC_RESIDENT_SLOTS");
+        int cap = rs ? atoi(rs) : std::max(prop.multiProcessorCount - 24, 1);
+        cap = cap < 1 ? 1 : (cap > prop.multiProcessorCount ? prop.multiProcessorCount : cap);
+        if (ctx->resident && stream_count > cap) stream_count = cap;
+        ctx->res_slots = stream_count;
+    }
+    {
         const char* e = getenv("SC_LAUNCH_STREAMS");
         int nl = e ? atoi(e) : 11;
         nl = nl < 1 ? 1 : (nl > 30 ? 30 : nl);
@@ -1344,6 +1488,8 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         const char* ps = getenv("SC_PINNED_STAGING");
         const bool want = ps ? atoi(ps) != 0 : stream_count > 1;
         ctx->arena_limit = want ? std::max(plan[0] + 1, 2) : 0;
+        ctx->setup_limit = std::max(1, (plan[0] + 1) / 2);
+        if (const char* e = getenv("SC_SETUP_LIMIT")) ctx->setup_limit = std::max(1, atoi(e));
     }
     // the slots' host-mapped parameter / result blocks: one allocation each for all slots
     const size_t ns = (size_t)stream_count;
@@ -1367,6 +1513,24 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         ctx->last_error = ex.what();
         sc_ctx_destroy(h);
         return SC_ERR_HIP;
+    }
+    if (ctx->resident) {
+        if (hipHostMalloc((void**)&ctx->mail_h, ns * sizeof(Mailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostMalloc((void**)&ctx->ctl_h, sizeof(ResidentCtl), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&ctx->mail_d, ctx->mail_h, 0) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&ctx->ctl_d, ctx->ctl_h, 0) != hipSuccess ||
+            hipStreamCreateWithFlags(&ctx->rstream, hipStreamNonBlocking) != hipSuccess) {
+            sc_ctx_destroy(h);
+            return SC_ERR_HIP;
+        }
+        std::memset(ctx->mail_h, 0, ns * sizeof(Mailbox));
+        std::memset(ctx->ctl_h, 0, sizeof(ResidentCtl));
+        ctx->heart = std::thread([ctx] {
+            while (!ctx->heart_stop.load(std::memory_order_acquire)) {
+                __atomic_fetch_add(&ctx->ctl_h->heartbeat, 1u, __ATOMIC_RELEASE);
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            }
+        });
     }
     const int dev = device;
     ctx->pool.reset(new FiberPool(plan[0], [dev] { (void)hipSetDevice(dev); }));
@@ -1397,6 +1561,12 @@ void sc_ctx_destroy(sc_ctx* h) {
     if (ctx->server.joinable()) ctx->server.join();
     if (ctx->pool) ctx->pool->shutdown();
     (void)hipSetDevice(ctx->device);
+    ctx->resident_shutdown();
+    ctx->heart_stop.store(true, std::memory_order_release);
+    if (ctx->heart.joinable()) ctx->heart.join();
+    if (ctx->rstream) (void)hipStreamDestroy(ctx->rstream);
+    if (ctx->mail_h) (void)hipHostFree(ctx->mail_h);
+    if (ctx->ctl_h) (void)hipHostFree(ctx->ctl_h);
     for (auto& w : ctx->workers) {
         for (hipEvent_t e : w->ev_pool) (void)hipEventDestroy(e);
         if (w->sync_ev) (void)hipEventDestroy(w->sync_ev);
@@ -1468,6 +1638,7 @@ int sc_roi_submit(sc_ctx* h, const char* ref_bases, int ref_len, const int* read
         job->handle = ctx->next_handle++;
         ctx->jobs[job->handle] = job;
         ctx->queue.push_back(job);
+        ctx->regions_active.fetch_add(1, std::memory_order_acq_rel);
         *handle_out = job->handle;
         if (!ctx->idle.empty()) { wake = ctx->idle.back(); ctx->idle.pop_back(); }
     }

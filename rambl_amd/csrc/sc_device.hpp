@@ -93,6 +93,31 @@ constexpr int MAXB = 48;
 struct LevelBatch { LevelItem it[MAXB]; };
 static_assert(sizeof(LevelItem) == 80 && sizeof(LevelBatch) <= 4096, "kernel-argument segment");
 
+// Resident level workers (k_level_resident): one workgroup per slot of the context stays on its CU while regions are in
+// flight and takes the slot's levels from a mailbox in host-mapped memory instead of being launched once per level.
+// The host writes `item`, then `seq` (release); the workgroup polls `seq`, runs the level, stamps LevelResult::seq as the
+// launched kernels do and polls again.  It ends when the context raises `stop` (no region in flight any more, or the
+// context is destroyed) or when the host's heartbeat stands still for `idle_ticks` (a host that has died or hangs).
+struct alignas(128) Mailbox {
+    LevelItem item;              // the level to run
+    unsigned seq;                // host: LevelHdr::seq of `item`, stored last
+    unsigned ack;                // host: the slot's last stamp before this generation of the grid was launched
+    unsigned state;              // kernel: 1 resident, 2 gone
+    unsigned levels;             // kernel: levels served by this generation (diagnostics)
+    unsigned pad[8];
+};
+static_assert(sizeof(Mailbox) == 128, "one mailbox per 128 bytes");
+struct ResidentCtl {
+    unsigned stop;               // host: nonzero -> every workgroup leaves after its current level
+    unsigned heartbeat;          // host: keeps changing while the context's server thread is alive
+    unsigned pad[30];
+};
+struct ResidentArgs {
+    Mailbox* mail;               // host-mapped, [slots]
+    const ResidentCtl* ctl;      // host-mapped
+    unsigned long long idle_ticks;   // 100 MHz ticks without a heartbeat change after which a workgroup gives up
+};
+
 // Per-level results, written by the kernel into host-mapped pinned memory; `seq` last (system-scope release).
 struct LevelResult {
     double abund[MAXS];          // HARD: sum of responsibilities; SAMPLE: urn weights a[] after the sweeps

@@ -78,10 +78,12 @@ public:
     // The fiber may run (again).  Callable from any thread, also before the fiber has finished parking.  Every
     // make_ready must be matched by exactly one park() / the fiber's start: a fiber that is made ready twice for one
     // park would be resumed a second time from wherever it parks next.
-    void make_ready(Fiber* f) {
+    // `later`: behind every fiber that was made ready the ordinary way -- for long, CPU-bound stretches (the set-up of
+    // a new region) that must not delay the short continuations of the regions whose levels are coming back.
+    void make_ready(Fiber* f, bool later = false) {
         {
             std::lock_guard<std::mutex> lk(mu_);
-            ready_.push_back(f);
+            (later ? later_ : ready_).push_back(f);
         }
         n_ready_.fetch_add(1, std::memory_order_release);
         if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_one();
@@ -95,7 +97,7 @@ public:
     // From inside a fiber: let the other ready fibers run first.
     static void yield() {
         Fiber* f = current();
-        f->pool->make_ready(f);
+        f->pool->make_ready(f, true);
         swapcontext(&f->ctx, f->back);
     }
     static Fiber*& current() { return tl_current(); }
@@ -143,15 +145,16 @@ private:
             if (n_ready_.load(std::memory_order_acquire) > 0) {
                 std::lock_guard<std::mutex> lk(mu_);
                 if (!ready_.empty()) { f = ready_.front(); ready_.pop_front(); n_ready_.fetch_sub(1, std::memory_order_relaxed); }
+                else if (!later_.empty()) { f = later_.front(); later_.pop_front(); n_ready_.fetch_sub(1, std::memory_order_relaxed); }
             }
             if (!f) {
                 // nothing ready: spin briefly (a level lasts ~0.5 ms, completions arrive all the time under load), then sleep
                 if (++spins < 2000) { __builtin_ia32_pause(); continue; }
                 std::unique_lock<std::mutex> lk(mu_);
-                if (stop_ && ready_.empty()) return;
-                if (ready_.empty()) {
+                if (stop_ && ready_.empty() && later_.empty()) return;
+                if (ready_.empty() && later_.empty()) {
                     sleepers_.fetch_add(1, std::memory_order_release);
-                    cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return stop_ || !ready_.empty(); });
+                    cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return stop_ || !ready_.empty() || !later_.empty(); });
                     sleepers_.fetch_sub(1, std::memory_order_release);
                 }
                 spins = 0;
@@ -177,7 +180,7 @@ private:
     std::vector<std::thread> threads_;
     std::mutex mu_;
     std::condition_variable cv_;
-    std::deque<Fiber*> ready_;
+    std::deque<Fiber*> ready_, later_;
     std::vector<Fiber*> all_;
     std::atomic<int> n_ready_{0}, sleepers_{0}, running_{0}, max_running_{0};
     std::atomic<long> switches_{0};

@@ -458,6 +458,34 @@ __device__ __forceinline__ void urn_chain_q(const JD& job, const LevelHdr& h, co
     }
 }
 
+// What the wavefronts that do NOT run the chain do meanwhile, where they may not simply end (a resident workgroup, and
+// the variants behind k_level_any that it shares): an s_barrier counts every live wavefront of the workgroup, so they
+// take part in exactly the barriers of urn_chain_q -- the one after the uniforms are staged, the two of every pass (the
+// advance of the pass is read from s_x between them, as the chain's wavefronts read it), the one after the loop.
+template <int NW>
+__device__ __forceinline__ void urn_chain_shadow(const LevelHdr& h, const int* s_x) {
+    const int total = h.n_sweeps * h.Q;
+    __syncthreads();
+    int t = 0;
+#pragma unroll 1
+    while (t < total) {
+        lds_barrier();
+        int adv = 16 * NW;
+#pragma unroll
+        for (int j = 0; j < NW / 4; j++) {
+            const i4v xf = *(const volatile i4v*)(s_x + 4 * j);
+            adv = min(adv, min(min(xf.x, xf.y), min(xf.z, xf.w)));
+        }
+        const int rem = total - t;
+        adv = adv < rem ? adv : rem;
+        if (adv == 0) adv = 1;
+        t += adv;
+        if (t >= total) break;
+        lds_barrier();
+    }
+    __syncthreads();
+}
+
 // --------------------------------------------------------------------------
 // The pieces of one level of the walk (NonparametricClustering.cpp:284-458) that every mode shares.  They
 // run inside the level's single workgroup (k_level_sample / k_level); for levels with hundreds of thousands
@@ -743,7 +771,7 @@ __device__ __forceinline__ LevelHdr load_hdr(const IT& it) {
     h.copy_n = it.h.copy_n; h.seq = it.h.seq;
     return h;
 }
-template <int NB, bool ROWS_LDS, class IT>
+template <int NB, bool ROWS_LDS, bool STAY, class IT>
 __device__ __forceinline__ void level_sample_body(const IT& it, unsigned char* s_raw) {
     const unsigned long long wall0 = wall_clock64();
     const LevelHdr h = load_hdr(it);
@@ -837,9 +865,13 @@ __device__ __forceinline__ void level_sample_body(const IT& it, unsigned char* s
     __syncthreads();
     if (tid == 0) R->phase_ticks[4] = (unsigned)(wall_clock64() - wall0);
     constexpr int NW = chain_nw(NB);
-    if (tid >= 64 * NW) return;                            // a finished wavefront no longer counts at the barriers below
-    nt = 64 * NW;
-    urn_chain_q<NB, ROWS_LDS, NW>(job, h, l.s_sp, R, l.s_slot, l.s_a, l.s_p, l.s_kf, l.s_a0f, l.s_cnt, l.s_x, s_uwin, s_rows, stride, tid);
+    if (tid >= 64 * NW) {
+        if (!STAY) return;                                 // a finished wavefront no longer counts at the barriers below
+        urn_chain_shadow<NW>(h, l.s_x);                    // ... one that has to stay takes part in them
+    } else {
+        urn_chain_q<NB, ROWS_LDS, NW>(job, h, l.s_sp, R, l.s_slot, l.s_a, l.s_p, l.s_kf, l.s_a0f, l.s_cnt, l.s_x, s_uwin, s_rows, stride, tid);
+    }
+    if (!STAY) nt = 64 * NW;
     __syncthreads();
     for (int i = tid; i < S * KMAX; i += nt) R->cnt[i] = l.s_cnt[i];
     finish_level(h, R, wall0, tid);
@@ -981,7 +1013,7 @@ __device__ __forceinline__ void level_plain_body(const IT& it, unsigned char* s_
 template <int NB, bool ROWS_LDS>
 __global__ __launch_bounds__(CHAIN_THREADS) void k_level_sample(LevelBatch batch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    level_sample_body<NB, ROWS_LDS>(batch.it[blockIdx.x], s_raw);
+    level_sample_body<NB, ROWS_LDS, false>(batch.it[blockIdx.x], s_raw);
 }
 __global__ __launch_bounds__(512) void k_level(LevelBatch batch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -994,16 +1026,15 @@ __global__ __launch_bounds__(512) void k_level(LevelBatch batch) {
 // 56 scalars into the sampler's pass loop), reading the item through the constant address space like kernel arguments.
 typedef const __attribute__((address_space(4))) LevelItem KItem;
 template <int NB, bool ROWS_LDS>
-__device__ __noinline__ void level_sample_call(KItem* it) {
+__device__ __noinline__ void level_sample_call(const LevelItem* it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    level_sample_body<NB, ROWS_LDS>(*it, s_raw);
+    level_sample_body<NB, ROWS_LDS, true>(*it, s_raw);      // every wavefront stays to the end (shared with the resident workgroups)
 }
-__device__ __noinline__ void level_plain_call(KItem* it) {
+__device__ __noinline__ void level_plain_call(const LevelItem* it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     level_plain_body(*it, s_raw);
 }
-__global__ __launch_bounds__(CHAIN_THREADS) void k_level_any(LevelBatch batch) {
-    KItem* it = (KItem*)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.x;      // batch is the only argument
+__device__ __forceinline__ void level_dispatch(const LevelItem* it) {
     const int kind = it->kind & 0xFF;                                             // (the upper bits carry the item's LDS need)
     if (kind == 0) { level_plain_call(it); return; }
     const bool wl = (kind - 1) & 1;
@@ -1013,7 +1044,76 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_level_any(LevelBatch batch) {
         default: if (wl) level_sample_call<8, true>(it); else level_sample_call<8, false>(it);
     }
 #undef SC_ANY
+}
+__global__ __launch_bounds__(CHAIN_THREADS) void k_level_any(LevelBatch batch) {
+    __shared__ LevelItem s_item;                                                  // the variants read their item through a generic pointer
+    KItem* it = (KItem*)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.x;      // batch is the only argument
+    if (threadIdx.x < sizeof(LevelItem) / 4) reinterpret_cast<unsigned*>(&s_item)[threadIdx.x] = reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(it)[threadIdx.x];
+    __syncthreads();
+    level_dispatch(&s_item);
     (void)batch;
+}
+
+// Resident level workers: workgroup b serves slot b of the context (see Mailbox in sc_device.hpp).  Wavefront 0 polls
+// the slot's mailbox over PCIe (a relaxed system-scope load, then a nap that grows to ~3 us), the other wavefronts wait
+// at the workgroup barrier.  A new level: one system-scope acquire (the arrays of a new region arrive by DMA while this
+// workgroup stays on its CU: its L1 must not serve lines of the region before) and a scalar-cache invalidate (the
+// region's JobDev block is read through the constant address space), then the item goes to LDS and the variant it names
+// runs exactly as it does behind k_level_any.  Every wavefront reaches the exit: `stop`, or a heartbeat that stands still.
+__global__ __launch_bounds__(CHAIN_THREADS) void k_level_resident(ResidentArgs a) {
+    __shared__ __attribute__((aligned(16))) LevelItem s_item;
+    __shared__ int s_cmd;
+    Mailbox* mb = a.mail + blockIdx.x;
+    const int tid = threadIdx.x;
+    unsigned last = 0, served = 0;
+    if (tid == 0) {
+        last = __hip_atomic_load(&mb->ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mb->state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (;;) {
+        if (tid == 0) {
+            int cmd = 0;
+            unsigned naps = 0;
+            unsigned long long t_hb = wall_clock64();
+            unsigned hb0 = __hip_atomic_load(&a.ctl->heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (;;) {
+                const unsigned sq = __hip_atomic_load(&mb->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (sq != last) { cmd = 1; break; }
+                if ((naps & 15u) == 15u) {
+                    if (__hip_atomic_load(&a.ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
+                    const unsigned hb = __hip_atomic_load(&a.ctl->heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const unsigned long long now = wall_clock64();
+                    if (hb != hb0) { hb0 = hb; t_hb = now; }
+                    else if (now - t_hb > a.idle_ticks) break;           // nobody is there any more
+                }
+                naps++;
+                if (naps < 32) __builtin_amdgcn_s_sleep(4);
+                else if (naps < 256) __builtin_amdgcn_s_sleep(32);
+                else __builtin_amdgcn_s_sleep(127);
+            }
+            if (cmd) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                __builtin_amdgcn_s_dcache_inv();
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const volatile u4v* src = reinterpret_cast<const volatile u4v*>(&mb->item);      // five 16-byte reads over PCIe
+                u4v* dst = reinterpret_cast<u4v*>(&s_item);
+                static_assert(sizeof(LevelItem) == 80 && alignof(Mailbox) >= 8, "mailbox item");
+#pragma unroll
+                for (int i = 0; i < 5; i++) dst[i] = src[i];
+                last = s_item.h.seq;
+                served++;
+            }
+            s_cmd = cmd;
+        }
+        __syncthreads();
+        if (!s_cmd) break;
+        level_dispatch(&s_item);
+        __syncthreads();                                   // the level is stamped; s_item and s_cmd may be rewritten
+    }
+    if (tid == 0) {
+        __hip_atomic_store(&mb->levels, served, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mb->state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 // --------------------------------------------------------------------------
 // a7/a8: progressive sum-of-pairs MSA, MultipleSequenceAlignmentSP.cpp:10-301,
@@ -1344,6 +1444,7 @@ template <int NB, bool L> static int set_sample_attr() {
 int init_kernels() {
     int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEVEL_LDS);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_any), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_resident), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msa<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSA_LDS);
     rc |= set_sample_attr<1, true>(); rc |= set_sample_attr<1, false>();
     rc |= set_sample_attr<2, true>(); rc |= set_sample_attr<2, false>();
@@ -1444,6 +1545,10 @@ void launch_level_batch(hipStream_t st, int kind, const LevelBatch& b, int n) {
                  else hipLaunchKernelGGL((k_level_sample<8, false>), dim3(n), dim3(CHAIN_THREADS), lds, st, b);
     }
 #undef SC_SAMPLE
+}
+// one grid of `slots` resident workgroups, each with the whole LDS of its CU (every variant must fit)
+void launch_resident(hipStream_t st, const ResidentArgs& a, int slots) {
+    hipLaunchKernelGGL(k_level_resident, dim3(slots), dim3(CHAIN_THREADS), CHAIN_LDS, st, a);
 }
 void launch_msa(hipStream_t st, const MsaDev& d) {
     if (d.cmax > MSA_CM || d.mv_stride > 64) hipLaunchKernelGGL(k_msa<true>, dim3(1), dim3(256), 0, st, d);      // state in HBM scratch

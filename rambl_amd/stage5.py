@@ -166,7 +166,9 @@ def run_regions(ctx, prepared, streams=1, params=None, errors=None):
             except capi.StrainCallError as e:
                 fail(idx, "%s:%d-%d" % window, str(e))
                 continue
-            drain(max(streams, 1))
+            # a few more than the context has slots: the library queues them, so a slot that falls free finds its next
+            # region at once even when the oldest region in flight (the one waited for here) is a slow one
+            drain(max(streams, 1) + max(2, streams // 4))
     drain(0)
     return ["".join(t for _, t in sorted(x)) for x in texts], stats
 

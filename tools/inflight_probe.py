@@ -49,8 +49,13 @@ def main():
     reads = int(os.environ.get("SC_PROBE_READS", "10000"))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("SC_PROBE_QUEUES", "24"))
     from rambl_amd import capi, stage5
-    prep = prepare(max(rs), reads)
+    # distinct data sets (seeds 21..), reused cyclically; SC_PROBE_ROUNDS x R regions pass through the context with R in
+    # flight, so that the ramp at the start and the drain at the end weigh 1 / rounds (the steady state is what a node sees)
+    distinct = int(os.environ.get("SC_PROBE_DISTINCT", "48"))
+    rounds = int(os.environ.get("SC_PROBE_ROUNDS", "1"))
+    base = prepare(min(max(rs), distinct), reads)
     for r in rs:
+        prep = [base[i % len(base)] for i in range(r * rounds)]
         ctx = capi.Context(0, r)
         params = capi.default_params(0.01, 0.02, 0.02)
         # warm every slot (device buffers are allocated on a slot's first region: SC_PROBE_WARM_ALL=0 leaves that in the clock)
@@ -61,12 +66,13 @@ def main():
         import resource
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.time()
-        _, stats = stage5.run_regions(ctx, prep[:r], r, params)
+        _, stats = stage5.run_regions(ctx, prep, r, params)
         t_end = time.time()
         dt = t_end - t0
         ctx.close()
         n = len(stats)
-        rec = dict(regions=r, seconds=round(dt, 3), reads_per_s=round(r * reads / dt),
+        rec = dict(regions=len(prep), in_flight=r, seconds=round(dt, 3), reads_per_s=round(len(prep) * reads / dt),
+                   resident=os.environ.get("SC_RESIDENT", "0"),
                    cluster_ms=round(sum(s["cluster_ms"] for s in stats) / n, 1),
                    graph_ms=round(sum(s["graph_ms"] for s in stats) / n, 1),
                    level_kernel_ms=round(sum(s["level_kernel_ticks"] for s in stats) / n / 1e5, 1),
@@ -78,6 +84,8 @@ def main():
         rec["cpu_cores_used"] = round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / dt, 2)
         rec["t_end"] = t_end
         rec["gap_us_per_level"] = round(1e3 * (rec["cluster_ms"] - rec["level_kernel_ms"]) / max(rec["levels"], 1), 1)
+        # share of the GPU's 256 CUs that held a level workgroup, averaged over the run
+        rec["cu_busy_frac"] = round(sum(s["level_kernel_ticks"] for s in stats) / 1e5 / 1e3 / (256 * dt), 3)
         print(json.dumps(rec), flush=True)
 
 
