@@ -149,6 +149,10 @@ typedef struct sc_aln sc_aln;
 typedef struct sc_reads sc_reads;
 
 int sc_aln_open(const char* path, sc_aln** out);     /* on a parse error *out still carries the message */
+/* The same, keeping the records of the named references only (n_names = 0: of none; n_names < 0: of all) while
+ * sc_aln_ref_stats still answers for every reference of the file: a rank of a multi-GPU run opens the file once without
+ * records to price the regions, and once with the names of its own shard (rambl_amd/stage5.py). */
+int sc_aln_open_filtered(const char* path, const char* const* names, int n_names, sc_aln** out);
 void sc_aln_close(sc_aln* aln);
 const char* sc_aln_error(sc_aln* aln);
 long sc_aln_records(sc_aln* aln);
@@ -178,15 +182,18 @@ void sc_reads_free(sc_reads* reads);
  * /root/reference/scripts/coverage_all_samples.py:21-186 pipes `samtools depth <bams>` (per-base depth per file,
  * deleted and skipped bases not counted, flags 0x704 excluded) through awk (sum over the files), sort and
  * `bedtools merge -c 4 -o mean -d 10` (one-base records [p, p+1) merged while at most 10 uncovered bases separate
- * them; mean of the merged depths).  sc_depth_scan does the same from alignment files the library has read:
+ * them; mean of the merged depths).  sc_depth_scan does the same from alignment files the library has read (one
+ * kernel: the per-base depth never exists in HBM, a wavefront builds it for its reference in LDS):
  * intervals come back sorted by (reference index, start), 1-based inclusive, with the sum of the depths of their
  * covered positions and their number (mean = sum / n).  Returns SC_ERR_CAPACITY (with *n_intervals set) when `cap`
  * is too small.  samtools' per-file depth cap (8000) is not applied; parity at that tool boundary is unpinned. */
 typedef struct sc_depth_stats {
-    long cells;            /* cells of the difference array (reference bases + padding) */
-    long runs;             /* aligned runs (CIGAR M = X operations) marked */
-    double mark_ms;        /* clearing the array + k_depth_mark, HIP events */
-    double segments_ms;    /* k_depth_segments, HIP events: streams 4 bytes per cell */
+    long cells;            /* reference bases scanned */
+    long runs;             /* aligned runs (CIGAR M = X operations) */
+    double extract_ms;     /* host: CIGAR walk of the records -> runs, on the rank's host threads (sc_depth_scan only) */
+    double prepare_ms;     /* host: runs bucketed by reference into page-locked memory (+ start order inside long references) */
+    double upload_ms;      /* HIP events: runs (8 bytes each) and the reference tables to the device */
+    double kernel_ms;      /* HIP events: k_depth_fused (difference array in LDS -> depths -> intervals) */
 } sc_depth_stats;
 int sc_depth_scan(int device, sc_aln* const* alns, int n_alns, const char* const* ref_names, const int* ref_len, int n_refs,
                   int max_gap, int* iv_ref, int* iv_start, int* iv_end, long* iv_sum, int* iv_n, int cap, int* n_intervals,

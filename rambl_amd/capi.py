@@ -63,6 +63,8 @@ def load_library():
     lib.sc_roi_thread_tables.argtypes = [vp, C.c_int, ip, ip, C.c_int, ip, C.c_long, C.c_char_p, ip, C.POINTER(C.c_long)]
     pi, pc, pu = C.POINTER(ip), C.POINTER(C.c_char_p), C.POINTER(C.c_ubyte)
     lib.sc_aln_open.argtypes = [cp, C.POINTER(vp)]
+    lib.sc_aln_open_filtered.argtypes = [cp, C.POINTER(C.c_char_p), C.c_int, C.POINTER(vp)]
+    lib.sc_aln_open_filtered.restype = C.c_int
     lib.sc_aln_close.argtypes = [vp]
     lib.sc_aln_close.restype = None
     lib.sc_aln_error.argtypes = [vp]
@@ -86,7 +88,7 @@ def load_library():
 
 EXPORTS = ["sc_ctx_create", "sc_ctx_destroy", "sc_last_error", "sc_roi_error", "sc_host_plan", "sc_roi_submit", "sc_roi_wait", "sc_roi_result",
            "sc_roi_graph_dump", "sc_roi_trace", "sc_roi_stats", "sc_roi_release", "sc_roi_edge_support", "sc_msa_align",
-           "sc_roi_thread_tables", "sc_aln_open", "sc_aln_close", "sc_aln_error", "sc_aln_records", "sc_aln_ref_stats", "sc_aln_pileup_flags",
+           "sc_roi_thread_tables", "sc_aln_open", "sc_aln_open_filtered", "sc_aln_close", "sc_aln_error", "sc_aln_records", "sc_aln_ref_stats", "sc_aln_pileup_flags",
            "sc_aln_load_reads", "sc_reads_get", "sc_reads_free", "sc_depth_scan", "sc_depth_scan_runs"]
 
 
@@ -189,10 +191,15 @@ class NativeReads:
 class NativeAln:
     """An alignment file (SAM text or BAM) read and indexed by the library (sc_aln_*)."""
 
-    def __init__(self, path):
+    def __init__(self, path, only=None):
+        """only: keep the records of these references only ([]: of none -- statistics for pricing the regions; None: all)."""
         self.path = path
         self._h = C.c_void_p()
-        rc = lib().sc_aln_open(path.encode(), C.byref(self._h))
+        if only is None:
+            rc = lib().sc_aln_open(path.encode(), C.byref(self._h))
+        else:
+            names = (C.c_char_p * max(len(only), 1))(*[n.encode() for n in only])
+            rc = lib().sc_aln_open_filtered(path.encode(), names, len(only), C.byref(self._h))
         if rc != SC_OK:
             msg = lib().sc_aln_error(self._h).decode() if self._h else "cannot open"
             self.close()

@@ -384,10 +384,14 @@ void Worker::init() {
 void Worker::sync_stream() {
     if (!FiberPool::in_fiber() || ctx->workers.size() <= 1) { HIPCHK(hipStreamSynchronize(st)); return; }
     HIPCHK(hipEventRecord(sync_ev, st));
-    for (;;) {
+    const double t0 = now_ms();
+    for (unsigned spins = 0;; spins++) {
         const hipError_t e = hipEventQuery(sync_ev);
         if (e == hipSuccess) return;
         if (e != hipErrorNotReady) throw HipError(std::string("set-up stream: ") + hipGetErrorString(e));
+        // a set-up stream that makes no progress for minutes is stuck (e.g. queued behind something that waits for this
+        // region): an error for this region, not a hang of the process
+        if ((spins & 0x3FFu) == 0x3FFu && now_ms() - t0 > 180000.0) throw HipError("set-up stream: no progress for 3 minutes");
         FiberPool::yield();
     }
 }
@@ -550,7 +554,9 @@ void Ctx::setup_enter() {
 }
 // A level is about to be posted to slot w->slot: make sure a generation of the resident grid is there to take it.
 void Ctx::resident_ensure(Worker* w) {
+    const double t0 = now_ms();
     for (;;) {
+        if (now_ms() - t0 > 60000.0) throw HipError("resident level workers: the previous grid has not left after a minute");
         {
             std::lock_guard<std::mutex> lk(gen_mu);
             if (gen_state == GEN_RUNNING) {
@@ -1466,10 +1472,20 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         if (ctx->resident && stream_count > cap) stream_count = cap;
         ctx->res_slots = stream_count;
     }
+    if (ctx->resident) {
+        // The resident grid stays in its hardware queue for as long as regions are in flight: nothing else may ever be
+        // queued behind it (a set-up kernel of a region behind the grid that waits for that region's levels would never
+        // start).  Streams share hardware queues once there are more streams than queues, and queues are kept per
+        // priority: the grid's stream is the only one of its priority, and this context creates few other streams.
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&ctx->rstream, hipStreamNonBlocking, hi) != hipSuccess) { sc_ctx_destroy(h); return SC_ERR_HIP; }
+    }
     {
         const char* e = getenv("SC_LAUNCH_STREAMS");
         int nl = e ? atoi(e) : 11;
         nl = nl < 1 ? 1 : (nl > 30 ? 30 : nl);
+        if (ctx->resident) nl = 1;                 // levels are not launched: one stream for the rare grid kernels of huge levels
         if (nl > stream_count) nl = stream_count;
         const int nset = stream_count >= 8 ? 4 : (stream_count > 1 ? 2 : 1);      // 11 + 4 + the null stream = 16 hardware queues
         ctx->lstreams.resize((size_t)nl);
@@ -1518,8 +1534,7 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         if (hipHostMalloc((void**)&ctx->mail_h, ns * sizeof(Mailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostMalloc((void**)&ctx->ctl_h, sizeof(ResidentCtl), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostGetDevicePointer((void**)&ctx->mail_d, ctx->mail_h, 0) != hipSuccess ||
-            hipHostGetDevicePointer((void**)&ctx->ctl_d, ctx->ctl_h, 0) != hipSuccess ||
-            hipStreamCreateWithFlags(&ctx->rstream, hipStreamNonBlocking) != hipSuccess) {
+            hipHostGetDevicePointer((void**)&ctx->ctl_d, ctx->ctl_h, 0) != hipSuccess) {
             sc_ctx_destroy(h);
             return SC_ERR_HIP;
         }

@@ -105,11 +105,21 @@ struct Mt19937 {                                       // std::mt19937 + generat
 
 namespace {
 
-bool load_sam_text(sc_aln& a, const char* text, size_t len) {
-    const char* p = text;
-    const char* end = text + len;
+int inflate_threads();
+// One stretch of the text (whole lines): the records of the references this handle keeps, per reference in file order,
+// and the statistics of every reference.
+struct SamPart {
+    std::vector<std::pair<std::string, std::vector<Rec>>> buckets;      // in order of first appearance
+    std::unordered_map<std::string, size_t> index;
+    std::unordered_map<std::string, sc_aln::RefStat> stats;
+    long n_records = 0;
+    std::string error;
+};
+bool parse_sam_part(const sc_aln& a, const char* p, const char* end, SamPart& out) {
     std::string last_name;
     std::vector<Rec>* bucket = nullptr;
+    sc_aln::RefStat* stat = nullptr;
+    bool wanted = false;
     while (p < end) {
         const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
         const char* le = nl ? nl : end;
@@ -130,21 +140,61 @@ bool load_sam_text(sc_aln& a, const char* text, size_t len) {
                 r.qname = f[0]; r.qlen = (int)(fend(0) - f[0]);
                 bool ok = lead_int(f[1], (int)(fend(1) - f[1]), r.flag) && lead_int(f[3], (int)(fend(3) - f[3]), r.pos) &&
                           lead_int(f[4], (int)(fend(4) - f[4]), r.mapq);
-                if (!ok) { a.error = "SAM record with a non-numeric FLAG, POS or MAPQ"; return false; }
+                if (!ok) { out.error = "SAM record with a non-numeric FLAG, POS or MAPQ"; return false; }
                 r.cigar = f[5]; r.clen = (int)(fend(5) - f[5]);
                 r.seq = f[9]; r.slen = (int)(fend(9) - f[9]);
                 r.quallen = (int)(qual_end - f[10]);
                 r.ref_end = ref_span_end(r.pos, r.cigar, r.clen);
                 const size_t rl = (size_t)(fend(2) - f[2]);
-                if (!bucket || last_name.size() != rl || memcmp(last_name.data(), f[2], rl) != 0) {
+                if (!stat || last_name.size() != rl || memcmp(last_name.data(), f[2], rl) != 0) {
                     last_name.assign(f[2], rl);
-                    bucket = &a.by_ref[last_name];
+                    stat = &out.stats[last_name];
+                    wanted = a.wants(f[2], rl);
+                    bucket = nullptr;
+                    if (wanted) {
+                        auto it = out.index.find(last_name);
+                        if (it == out.index.end()) { it = out.index.emplace(last_name, out.buckets.size()).first; out.buckets.emplace_back(last_name, std::vector<Rec>()); }
+                        bucket = &out.buckets[it->second].second;
+                    }
                 }
-                bucket->push_back(r);
-                a.n_records++;
+                stat->n++; stat->bases += (long)(r.ref_end - r.pos + 1);
+                if (wanted) bucket->push_back(r);
+                out.n_records++;
             }
         }
         p = next;
+    }
+    return true;
+}
+// The text is cut at line ends into as many stretches as this rank has host threads; the stretches are parsed side by
+// side and joined in file order (a reference's records keep the order of the file).
+bool load_sam_text(sc_aln& a, const char* text, size_t len) {
+    int nt = inflate_threads();
+    size_t min_chunk = (size_t)1 << 20;                                   // a stretch below this is not worth a thread
+    if (const char* e = getenv("SC_INGEST_MIN_CHUNK")) min_chunk = (size_t)std::max(atol(e), 64L);
+    nt = (int)std::max<size_t>(std::min<size_t>((size_t)nt, len / min_chunk), 1);
+    std::vector<const char*> cut((size_t)nt + 1, text + len);
+    cut[0] = text;
+    for (int k = 1; k < nt; k++) {
+        const char* q = text + len / (size_t)nt * (size_t)k;
+        if (q < cut[(size_t)k - 1]) q = cut[(size_t)k - 1];
+        const char* nl = (const char*)memchr(q, '\n', (size_t)(text + len - q));
+        cut[(size_t)k] = nl ? nl + 1 : text + len;
+    }
+    std::vector<SamPart> parts((size_t)nt);
+    std::vector<char> ok((size_t)nt, 1);
+    std::vector<std::thread> pool;
+    for (int k = 1; k < nt; k++) pool.emplace_back([&, k] { ok[(size_t)k] = parse_sam_part(a, cut[(size_t)k], cut[(size_t)k + 1], parts[(size_t)k]) ? 1 : 0; });
+    ok[0] = parse_sam_part(a, cut[0], cut[1], parts[0]) ? 1 : 0;
+    for (auto& th : pool) th.join();
+    for (int k = 0; k < nt; k++) {
+        if (!ok[(size_t)k]) { a.error = parts[(size_t)k].error; return false; }
+        for (auto& b : parts[(size_t)k].buckets) {
+            std::vector<Rec>& dst = a.by_ref[b.first];
+            if (dst.empty()) dst.swap(b.second); else dst.insert(dst.end(), b.second.begin(), b.second.end());
+        }
+        for (auto& st : parts[(size_t)k].stats) { sc_aln::RefStat& d = a.stats[st.first]; d.n += st.second.n; d.bases += st.second.bases; }
+        a.n_records += parts[(size_t)k].n_records;
     }
     return true;
 }
@@ -235,6 +285,7 @@ bool load_bam(sc_aln& a, const unsigned char* src, size_t n) {
         o += (size_t)l_name + 4;
     }
     static const char SEQ[] = "=ACMGRSVTWYHKDBN", CIG[] = "MIDNSHP=X???????";
+    const std::string star("*");
     while (o + 4 <= d.size()) {
         const int block = i32(o);
         o += 4;
@@ -245,6 +296,21 @@ bool load_bam(sc_aln& a, const unsigned char* src, size_t n) {
         const int l_seq = i32(o + 16);
         size_t p = o + 32;
         if (l_seq < 0 || p + l_read_name + 4ul * n_cigar + (size_t)(l_seq + 1) / 2 + (size_t)l_seq > o + (size_t)block) { a.error = "corrupt BAM record"; return false; }
+        const std::string& rname = (ref_id >= 0 && ref_id < n_ref) ? refs[(size_t)ref_id] : star;
+        if (!a.wants(rname.data(), rname.size())) {
+            // not this rank's reference: its statistics only (reference span of the CIGAR, as ref_span_end counts it)
+            long tot = 0;
+            for (unsigned k = 0; k < n_cigar; k++) {
+                uint32_t c; memcpy(&c, d.data() + p + l_read_name + 4ul * k, 4);
+                const unsigned op = c & 15;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) tot += (long)(c >> 4);
+            }
+            sc_aln::RefStat& st = a.stats[rname];
+            st.n++; st.bases += tot > 1 ? tot : 1;
+            a.n_records++;
+            o += (size_t)block;
+            continue;
+        }
         Rec r{};
         r.qlen = l_read_name ? (int)l_read_name - 1 : 0;
         char* qn = a.alloc((size_t)r.qlen + 1);
@@ -270,7 +336,8 @@ bool load_bam(sc_aln& a, const unsigned char* src, size_t n) {
         r.quallen = (l_seq == 0 || d[p] == 0xff) ? 1 : l_seq;            // "*" when absent
         r.flag = (int)flag; r.pos = pos + 1; r.mapq = (int)mapq;
         r.ref_end = ref_span_end(r.pos, r.cigar, r.clen);
-        a.by_ref[(ref_id >= 0 && ref_id < n_ref) ? refs[(size_t)ref_id] : std::string("*")].push_back(r);
+        a.by_ref[rname].push_back(r);
+        { sc_aln::RefStat& st = a.stats[rname]; st.n++; st.bases += (long)(r.ref_end - r.pos + 1); }
         a.n_records++;
         o += (size_t)block;
     }
@@ -355,10 +422,16 @@ struct sc_reads {
 
 extern "C" {
 
-int sc_aln_open(const char* path, sc_aln** out) {
-    if (!path || !out) return SC_ERR_ARG;
+int sc_aln_open(const char* path, sc_aln** out) { return sc_aln_open_filtered(path, nullptr, -1, out); }
+
+int sc_aln_open_filtered(const char* path, const char* const* names, int n_names, sc_aln** out) {
+    if (!path || !out || (n_names > 0 && !names)) return SC_ERR_ARG;
     *out = nullptr;
     std::unique_ptr<sc_aln> a(new sc_aln());
+    if (n_names >= 0) {
+        a->keep_all = false;
+        for (int i = 0; i < n_names; i++) if (names[i]) a->keep.insert(names[i]);
+    }
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return SC_ERR_ARG;
     struct stat stt;
@@ -400,11 +473,8 @@ long sc_aln_records(sc_aln* a) { return a ? a->n_records : 0; }
 int sc_aln_ref_stats(sc_aln* a, const char* gene, long* n_records, long* aligned_bases) {
     if (!a || !gene) return SC_ERR_ARG;
     long n = 0, b = 0;
-    auto it = a->by_ref.find(gene);
-    if (it != a->by_ref.end()) {
-        n = (long)it->second.size();
-        for (const Rec& r : it->second) b += (long)(r.ref_end - r.pos + 1);
-    }
+    auto it = a->stats.find(gene);
+    if (it != a->stats.end()) { n = it->second.n; b = it->second.bases; }
     if (n_records) *n_records = n;
     if (aligned_bases) *aligned_bases = b;
     return SC_OK;

@@ -6,6 +6,7 @@
 #include <memory>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace sc_ingest {
@@ -24,6 +25,13 @@ struct sc_aln {
     std::vector<std::unique_ptr<char[]>> arenas; size_t arena_used = 0, arena_cap = 0;
     std::unordered_map<std::string, std::vector<sc_ingest::Rec>> by_ref;      // records of a reference, in file order
     long n_records = 0;
+    // what a scheduler prices a region with, for EVERY reference of the file -- also for those whose records were not
+    // kept (sc_aln_open_filtered: a rank of a multi-GPU run keeps the records of its own shard only)
+    struct RefStat { long n = 0, bases = 0; };
+    std::unordered_map<std::string, RefStat> stats;
+    bool keep_all = true;
+    std::unordered_set<std::string> keep;                                     // references whose records are kept when !keep_all
+    bool wants(const char* name, size_t n) const { return keep_all || keep.count(std::string(name, n)) != 0; }
 
     char* alloc(size_t n) {
         if (arena_used + n > arena_cap) {

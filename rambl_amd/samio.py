@@ -322,7 +322,9 @@ class Alignments:
     lines, parsed by the Python mirror in ingest.py.  SC_PY_INGEST=1 forces the Python mirror for SAM text / BAM
     too (kept as the second implementation the tests compare the native one with)."""
 
-    def __init__(self, path):
+    def __init__(self, path, only=None):
+        """only: reference names whose records the native reader keeps ([]: none, the per-reference statistics only;
+        None: all) -- a rank of a multi-GPU run prices every region, then keeps its own shard."""
         self.path = path
         import os
         self.bam = is_bam(path) and shutil.which("samtools") is not None and not os.environ.get("SC_NATIVE_BAM")
@@ -333,7 +335,7 @@ class Alignments:
                 self.sam = SamText(path, bam=is_bam(path))
             else:
                 from . import capi
-                self.native = capi.NativeAln(path)
+                self.native = capi.NativeAln(path, only)
 
     def _text(self):
         """The Python mirror of the file (tests and tools ask for pileup / view TEXT; the product path does not)."""

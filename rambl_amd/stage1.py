@@ -4,7 +4,8 @@ Mirror of /root/reference/scripts/coverage_all_samples.py (`coverage_all_samples
 by rambl.py:82-102): the per-base depth of every sample's BAM, summed over the samples, merged into intervals
 (gaps of at most 10 uncovered bases) with their mean depth -- printed as `chrom <TAB> start <TAB> end <TAB> mean`, the
 stdout of the reference's final `bedtools merge -c 4 -o mean -d 10`.  The alignment files are read by the library
-(sc_aln_open), the depth array and the interval reduction run on the device (sc_depth_scan, rambl_amd/csrc/sc_depth.hip).
+(sc_aln_open), the depths and the interval reduction run on the device in one kernel (sc_depth_scan, k_depth_fused in
+rambl_amd/csrc/sc_depth.hip: a wavefront per reference, its difference array in LDS).
 
 Parity at the samtools / bedtools boundary is unpinned (neither tool is in the image, the reference holds no fixture):
 samtools' per-file depth cap is not applied, and the mean is printed with bedtools' default precision as documented
@@ -25,7 +26,8 @@ def _numeric_key(name):
 
 
 class DepthStats(C.Structure):
-    _fields_ = [("cells", C.c_long), ("runs", C.c_long), ("mark_ms", C.c_double), ("segments_ms", C.c_double)]
+    _fields_ = [("cells", C.c_long), ("runs", C.c_long), ("extract_ms", C.c_double), ("prepare_ms", C.c_double),
+                ("upload_ms", C.c_double), ("kernel_ms", C.c_double)]
 
 
 def depth_intervals(paths, fai_path, max_gap=10, device=0, alns=None):

@@ -192,6 +192,23 @@ def region_costs(fai, aln, opts=None):
     return costs
 
 
+def shard_alignments(fai, bam, world, rank, opts=None):
+    """-> (this rank's region indices, the alignment file holding their records).  One rank: the file is read once.
+    Several ranks on one host: every rank prices all regions from a records-free pass over the file (the per-reference
+    statistics), takes its longest-processing-time-first shard, and keeps only the records of its own references --
+    an eighth of the memory and of the record work per rank at eight ranks (rambl.py:190-194 hands every region's
+    process the whole BAM through samtools)."""
+    if world <= 1:
+        aln = samio.Alignments(bam)
+        return lpt_shards(region_costs(fai, aln, opts), 1)[0], aln
+    probe = samio.Alignments(bam, only=[])
+    costs = region_costs(fai, probe, opts)
+    if probe.native is not None:
+        probe.native.close()
+    mine = lpt_shards(costs, world)[rank]
+    return mine, samio.Alignments(bam, only=[fai[i][0] for i in mine])
+
+
 def gather_fasta(local_texts, local_ids, n_units, dist=None, device=None):
     """Variable-length gather of per-region FASTA bytes to rank 0, returned in
     unit order (replaces `cat` in rambl.py:197-201).  dist=None: single process."""
@@ -245,10 +262,10 @@ def strain_call(fasta, bam, out_dir=None, prefix="rambl", opts=None, device=0, s
     from . import capi
     rois = roi_list(fasta + ".fai")
     fai = samio.read_fai(fasta + ".fai")
-    shared = (samio.Fasta(fasta), fai, samio.Alignments(bam))
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
-    mine = lpt_shards(region_costs(fai, shared[2], opts), world)[rank]
+    mine, aln = shard_alignments(fai, bam, world, rank, opts)
+    shared = (samio.Fasta(fasta), fai, aln)
     prepared = prepared_stream([rois[i] for i in mine], fasta, bam, opts, ingest_workers, shared)   # ingest overlaps the regions in flight
     errs = []
     if ctx is not None:

@@ -1,5 +1,5 @@
 """rambl.py stage 1 (depth and breadth of marker genes across samples): the oracle restatement on a hand-computed case
-(CPU), the device path (sc_depth_scan: k_depth_mark + k_depth_segments) against the oracle on random records (-m gpu)."""
+(CPU), the device path (sc_depth_scan: k_depth_fused) against the oracle on random records (-m gpu)."""
 import os
 import random
 import sys
@@ -70,7 +70,8 @@ def test_depth_scan_matches_oracle(seed, max_gap, tmp_path):
     clips, filtered flags) against the oracle: every interval with its depth sum and covered positions, exactly."""
     from rambl_amd import capi, stage1
     rng = random.Random(seed)
-    refs = [("%d" % (1000 + k), rng.choice([1, 2, 5, 63, 64, 65, 255, 256, 257, 700, 1500, 3000])) for k in range(40)]
+    # (2 047 / 2 048 / 2 049: either side of the LDS tile of a wavefront; 3 000 and 9 000: two and five tiles)
+    refs = [("%d" % (1000 + k), rng.choice([1, 2, 5, 63, 64, 65, 255, 256, 257, 700, 1500, 2047, 2048, 2049, 3000, 9000])) for k in range(40)]
     files, texts = _random_files(rng, 3, refs, 900)
     paths = []
     for i, t in enumerate(texts):
@@ -83,7 +84,7 @@ def test_depth_scan_matches_oracle(seed, max_gap, tmp_path):
     order = sorted(refs, key=lambda r: (stage1._numeric_key(r[0]), r[0]))
     exp = depth_oracle.stage1(files, order, max_gap=max_gap)
     assert got == [(order[ri][0], s, e, sm, n) for ri, s, e, sm, n in exp]
-    assert st["runs"] > 1000 and st["cells"] >= sum(l for _, l in refs)
+    assert st["runs"] > 1000 and st["cells"] == sum(l for _, l in refs) and st["kernel_ms"] > 0
     text = stage1.bed_text(got)
     assert text.count("\n") == len(exp)
 

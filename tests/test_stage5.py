@@ -146,3 +146,48 @@ def test_eight_ranks_fit_sixteen_cpus():
     out = subprocess.run([sys.executable, "-c", code], env={k: v for k, v in os.environ.items() if k != "LOCAL_WORLD_SIZE"},
                          stdout=subprocess.PIPE, check=True)
     assert out.stdout.decode().strip() == "(15, 1, 16)"
+
+
+def test_a_rank_keeps_the_records_of_its_own_shard(tmp_path):
+    """sc_aln_open_filtered: the per-reference statistics (what LPT prices regions with) cover every reference of the file
+    whatever is kept; the windows of a kept reference are ingested exactly as from the unfiltered file; a reference that
+    was not kept has no reads.  SAM text (parsed in stretches on several threads) and BAM."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sc_testlib as T
+    from rambl_amd import capi, samio, synth
+    genes = [synth.make_gene(900 + k, glen=400, n_strains=2, n_reads=300 + 200 * k, rlen=110, name="g%d" % k, paired=(k == 1)) for k in range(4)]
+    fa, sam = synth.write_dataset(str(tmp_path), genes)
+    bam = str(tmp_path / "reads.bam")
+    T.write_bam(sam, bam)
+    fai = samio.read_fai(fa + ".fai")
+    os.environ["SC_INGEST_THREADS"] = "3"
+    os.environ["SC_INGEST_MIN_CHUNK"] = "4096"            # the small text is still cut into three stretches
+    try:
+        for path in (sam, bam):
+            full = capi.NativeAln(path)
+            none = capi.NativeAln(path, only=[])
+            some = capi.NativeAln(path, only=["g1", "g3"])
+            for name, _ in fai:
+                assert none.ref_stats(name) == full.ref_stats(name) == some.ref_stats(name) and full.ref_stats(name)[0] > 0
+            assert none.records() == full.records() == some.records()
+            for name, ln in fai:
+                ln = int(ln)
+                want = full.load_reads("", name, 1, ln, 0, 70, 13, 800)
+                got = some.load_reads("", name, 1, ln, 0, 70, 13, 800)
+                if name in ("g1", "g3"):
+                    assert (got.pos, got.cigar, got.seq, got.copies, got.mates, got.n_input) == (want.pos, want.cigar, want.seq, want.copies, want.mates, want.n_input)
+                    assert some.pileup_flags(0, name, 1, ln) == full.pileup_flags(0, name, 1, ln)
+                else:
+                    assert len(got) == 0 and got.n_input == 0 and len(want) > 0
+                assert len(none.load_reads("", name, 1, ln, 0, 70, 13, 800)) == 0
+        # the shards of two ranks: every region once, each rank's file holds its own references
+        for rank in (0, 1):
+            mine, aln = stage5.shard_alignments(fai, sam, 2, rank)
+            assert sorted(mine + stage5.shard_alignments(fai, sam, 2, 1 - rank)[0]) == [0, 1, 2, 3]
+            for i, (name, ln) in enumerate(fai):
+                n = len(aln.native.load_reads("", name, 1, int(ln), 0, 70, 13, 800))
+                assert (n > 0) == (i in mine)
+    finally:
+        os.environ.pop("SC_INGEST_THREADS", None)
+        os.environ.pop("SC_INGEST_MIN_CHUNK", None)
