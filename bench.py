@@ -155,25 +155,27 @@ def spawn_ranks(a):
     return max(rcs)
 
 
-def roofline(all_stats, steps, world):
+def roofline(all_stats, steps, world, pmc_round="r03"):
     k_ms = sum(s["sampler_kernel_ms"] for s in all_stats)
     k_n = sum(s["sampler_launches"] for s in all_stats)
     k_copies = sum(s["sampler_read_copies"] for s in all_stats)
     draws = sum(s["draws"] for s in all_stats)
     timing = "HIP events around every sampler launch, on the stream it is launched on"
     if not k_ms:
-        # many regions in flight: levels of several regions leave as one grid, so the duration of one region's sampler level
-        # is the kernel's own 100 MHz wall clock from its start to its completion stamp
+        # resident level workers / many regions in flight: no launch per level, so the duration of a sampler level is the
+        # kernel's own 100 MHz wall clock from the start of the level to its completion stamp
         k_ms = sum(s["sampler_level_ticks"] for s in all_stats) / 1e5
-        timing = "the level kernels' own wall clock (s_memrealtime), start of the workgroup to its completion stamp"
+        timing = "the level kernels' own wall clock (s_memrealtime), start of the level to its completion stamp"
     avg_ms = k_ms / max(k_n, 1)
     achieved = (ALG_BYTES_PER_READ * k_copies / max(k_n, 1)) / (avg_ms * 1e-3) if k_n and k_ms else 0.0
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
-    if os.path.exists(pmc) and world == 1:
-        # HBM bytes per sampler launch from the committed rocprofv3 --pmc passes of this command
-        traffic = json.load(open(pmc)).get("sample_traffic_bytes_per_launch")
-        traffic_src = "profiles/r02/pmc_summary.json (separate FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes)"
+    for rnd in (pmc_round, "r02"):
+        pmc = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
+        if os.path.exists(pmc) and world == 1:
+            # HBM bytes per sampler launch from the committed rocprofv3 --pmc passes of this command
+            traffic = json.load(open(pmc)).get("sample_traffic_bytes_per_launch")
+            traffic_src = "profiles/%s/pmc_summary.json (separate FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes)" % rnd
+            break
     return {"bound": "hbm", "kernel": "sc::k_level_sample<NB,L> (one sampler level: read log-likelihood update, weight rows, urn chain)",
             "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": ALG_BYTES_PER_READ * k_copies / max(k_n, 1),
@@ -200,6 +202,76 @@ def breakdown(all_stats, steps):
             "avg_candidates_per_sampler_launch": sum(s["sampler_strains"] for s in all_stats) / max(k_n, 1)}
 
 
+N_CU = 256                    # MI355X_MICROARCH.md: CUs (a level workgroup holds one while it runs)
+
+
+def make_context(local, streams, resident):
+    """A context of `streams` region slots with resident level workers (one workgroup per slot polls a mailbox: no launch
+    per level) or with a launch per level (the level server batches the levels of the regions in flight)."""
+    from rambl_amd import capi
+    old = os.environ.get("SC_RESIDENT")
+    os.environ["SC_RESIDENT"] = "1" if resident else "0"
+    try:
+        return capi.Context(local, streams)
+    finally:
+        if old is None:
+            os.environ.pop("SC_RESIDENT", None)
+        else:
+            os.environ["SC_RESIDENT"] = old
+
+
+def shape_regions(dirname, n, seed0, reads=10000, glen=1500, strains=3):
+    """n regions of the configs[1] shape (the generator of the headline, seeds seed0, seed0 + 1, ...), ingested."""
+    from rambl_amd import cli, stage5, synth
+    out = []
+    for k in range(n):
+        g = synth.make_gene(seed0 + k, glen=glen, n_strains=strains, n_reads=reads, name="gene%d" % (seed0 + k))
+        fa, sam = synth.write_dataset(os.path.join(dirname, "s%d" % (seed0 + k)), [g])
+        pa = cli.parse_cmd_line(stage5.straincall_argv("%s:1-%d" % (g["name"], glen), fa, sam))
+        out.append((pa, cli.load_regions(pa)))
+    return out
+
+
+def run_in_flight(local, base, in_flight, rounds, resident, reads):
+    """`rounds` x `in_flight` regions (the data sets of `base`, cyclically) through a context with `in_flight` slots: what a
+    GPU sustains with that many regions in flight -- the ramp at the start and the drain at the end weigh 1 / rounds."""
+    import resource
+    from rambl_amd import stage5
+    ctx = make_context(local, in_flight, resident)
+    try:
+        slots = in_flight
+        prep = [base[i % len(base)] for i in range(in_flight * rounds)]
+        stage5.run_regions(ctx, prep[:in_flight], in_flight)                 # every slot has had a region (its device buffers exist)
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
+        t0 = time.time()
+        _, stats = stage5.run_regions(ctx, prep, in_flight)
+        dt = time.time() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    finally:
+        ctx.close()
+    busy = sum(s["level_kernel_ticks"] for s in stats) / 1e5 / 1e3 / dt        # level workgroups on the GPU, averaged over the run
+    n = max(len(stats), 1)
+    return {"in_flight": slots, "regions": len(prep), "seconds": dt, "reads_per_s": len(prep) * reads / dt, "busy_cus": busy,
+            "cu_busy_frac": busy / N_CU, "level_kernel_s_per_region": sum(s["level_kernel_ticks"] for s in stats) / 1e5 / 1e3 / n,
+            "region_latency_s": sum(s["cluster_ms"] + s["graph_ms"] for s in stats) / 1e3 / n,
+            "host_cores_used": ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / dt}
+
+
+def scaling_model(n_gpus, work_kernel_s, slowest_alone_s, busy_cus_sat, units, fixed_s=0.0):
+    """makespan >= max(slowest region alone, sum of work / (N x saturated rate)): the regions of a set share nothing, a GPU
+    runs `busy_cus_sat` level workgroups side by side when saturated, and no region finishes before its own chain of
+    dependent levels has been walked."""
+    out = {"inputs": {"work_level_kernel_seconds": work_kernel_s, "slowest_region_alone_s": slowest_alone_s,
+                      "saturated_busy_cus_per_gpu": busy_cus_sat, "units": units},
+           "formula": "makespan >= max(slowest region alone, work / (N x saturated busy CUs))", "by_gpus": {}}
+    for n in (1, 2, 4, 8):
+        t = max(slowest_alone_s, work_kernel_s / max(n * busy_cus_sat, 1e-9)) + fixed_s
+        out["by_gpus"][str(n)] = {"makespan_s": t, "value": units / t, "bound": "latency of the slowest region" if slowest_alone_s >= work_kernel_s / max(n * busy_cus_sat, 1e-9) else "throughput"}
+    if n_gpus:
+        out["this_run"] = out["by_gpus"].get(str(n_gpus))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,13 +284,18 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-set", action="store_true", help="N = 1: skip the 100-region leg (regions_in_flight)")
     ap.add_argument("--no-depth", action="store_true", help="N = 1: skip the stage-1 depth-scan leg (hbm_bound_kernel)")
-    ap.add_argument("--streams", type=int, default=128, help="regions in flight per GPU on the 100-region set")
+    ap.add_argument("--no-saturation", action="store_true", help="skip the saturation leg (regions of the configs[1] shape in flight)")
+    ap.add_argument("--launch-mode", action="store_true", help="one launch per level (the level server) instead of resident level workers")
+    ap.add_argument("--streams", type=int, default=232, help="regions in flight per GPU (slots of the context)")
+    ap.add_argument("--sat-points", default="64,128,232", help="N = 1: regions in flight of the saturation curve")
+    ap.add_argument("--sat-rounds", type=int, default=3)
+    ap.add_argument("--sat-distinct", type=int, default=32, help="distinct data sets of the saturation leg (reused cyclically)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
 
-    # the library's launch and setup streams want a hardware queue each; HIP reads this once, when it initialises
+    # the library's streams want a hardware queue each; HIP reads this once, when it initialises
     # (rambl_amd/__init__.py sets it too, but torch touches the device first here)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
@@ -227,6 +304,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))       # ranks of this run share the host: the library sizes its threads by it
     backend = os.environ.get("SC_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse N > 1 on a one-GPU box
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
@@ -235,6 +313,9 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
+    resident = not a.launch_mode
+    mode = "resident level workers (one workgroup per region slot takes its levels from a host-mapped mailbox)" if resident else \
+        "one launch per level (level server, batches on shared streams)"
 
     from rambl_amd import capi, cli, samio, stage5, synth
 
@@ -250,6 +331,13 @@ def main():
             return float(t.item())
         return dt
 
+    def sum_over_ranks(v):
+        if world > 1:
+            t = torch.tensor([v], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return float(t.item())
+        return v
+
     def region_set(dirname):
         """The configs[2] set: 100 seed genes in one FASTA + one SAM, ingested (rows a1-a4, native) for this rank's shard."""
         fa, sam = os.path.join(dirname, "seed_otus.fasta"), os.path.join(dirname, "reads.sam")
@@ -263,24 +351,34 @@ def main():
         t0 = time.time()
         mine, aln = stage5.shard_alignments(fai, sam, world, rank)       # a rank keeps the records of its own shard only
         shared = (samio.Fasta(fa), fai, aln)
-        prepared = list(stage5.prepared_stream([rois[i] for i in mine], fa, sam, None, 4, shared))
+        prepared = list(stage5.prepared_stream([rois[i] for i in mine], fa, sam, None, max(min(cpu_budget(), 8), 1), shared))
         ingest_s = time.time() - t0
         n_in = sum(r.n_input for _, regs in prepared for _, r in regs)
         n_graph = sum(sum(r.copies) for _, regs in prepared for _, r in regs)
         return rois, mine, prepared, ingest_s, n_in, n_graph, aln.native.records()       # (records of the whole file, kept or not)
 
     if world > 1:
-        # ---- configs[2]: the 100-region set sharded over the ranks
+        # ---- configs[2]: the 100-region set sharded over the ranks (strong scaling) ...
         d = os.path.join(tempfile.gettempdir(), "scbench_set_%s" % os.environ.get("MASTER_PORT", "0"))
         os.makedirs(d, exist_ok=True)
         rois, mine, prepared, ingest_s, n_in, n_graph, n_total = region_set(d)
         streams = min(a.streams, max(len(mine), 1))
-        ctx = capi.Context(local, streams)
+        ctx = make_context(local, streams, resident)
 
         def step():
             texts, stats = stage5.run_regions(ctx, prepared, streams)
             return stage5.gather_fasta(texts, mine, len(rois), dist, dev), stats
 
+        # the slowest region of the set, alone on a GPU: the floor of the set's makespan however many GPUs share it
+        # (rank 0 holds it: the longest-processing-time-first partition deals the costliest region first)
+        slowest_alone = 0.0
+        if prepared:
+            big = max(range(len(prepared)), key=lambda i: sum(sum(r.copies) for _, r in prepared[i][1]) if not isinstance(prepared[i], stage5.RegionFailure) else 0)
+            stage5.run_regions(ctx, [prepared[big]], 1)
+            t1 = time.time()
+            stage5.run_regions(ctx, [prepared[big]], 1)
+            slowest_alone = time.time() - t1
+        slowest_alone = max_over_ranks(slowest_alone)
         for _ in range(a.warmup):
             step()
         fence()
@@ -293,6 +391,24 @@ def main():
         dt = max_over_ranks(time.time() - t0)
         ingest_max = max_over_ranks(ingest_s)
         ctx.close()
+        work = sum_over_ranks(sum(s["level_kernel_ticks"] for s in all_stats) / 1e5 / 1e3 / a.steps)
+        # ---- ... and the same generator at a size that saturates every GPU (weak scaling): slots x rounds regions of the
+        # configs[1] shape per rank, seeds continued from rank to rank
+        sat = None
+        if not a.no_saturation:
+            ds = os.path.join(d, "sat%d" % rank)
+            os.makedirs(ds, exist_ok=True)
+            base = shape_regions(ds, a.sat_distinct, 1000 + rank * a.sat_distinct, a.reads, a.glen, a.strains)
+            fence()
+            t1 = time.time()
+            mine_sat = run_in_flight(local, base, a.streams, a.sat_rounds, resident, a.reads)
+            fence()
+            dts = max_over_ranks(time.time() - t1)
+            busy_min = -max_over_ranks(-mine_sat["busy_cus"])
+            sat = {"workload": "%d ranks x %d regions of the configs[1] shape (%d distinct data sets per rank, seeds 1000 + %d * rank ...), %d in flight per GPU" % (
+                       world, mine_sat["regions"], a.sat_distinct, a.sat_distinct, a.streams),
+                   "scaling": "weak", "value": sum_over_ranks(mine_sat["regions"] * a.reads) / dts, "unit": "reads/s",
+                   "seconds_max_over_ranks_incl_warm_pass": dts, "rank0": mine_sat, "min_busy_cus_over_ranks": busy_min}
         if rank == 0:
             line = {"metric": "reads/sec into POA (150bp, ~1.5k-node graph)", "value": n_total * a.steps / dt, "unit": "reads/s",
                     "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -300,13 +416,20 @@ def main():
                     "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                     "config": {"workload": "configs[2]: 100 seed genes x 1500 bp (seeds 100-199), 2000-10000 x 150bp reads each, %d alignments "
                                            "in one FASTA + one SAM, rambl.py options (%s)" % (n_total, RAMBL_OPTS),
-                               "regions": len(rois), "regions_in_flight_per_gpu": streams,
+                               "regions": len(rois), "regions_in_flight_per_gpu": streams, "level_execution": mode,
                                "parallelism": "regions sharded LPT over %d ranks, no exchange while they run, FASTA gather over %s" % (
                                    world, "RCCL" if backend == "nccl" else backend)},
                     "rank0": {"regions": len(mine), "alignments": n_in, "read_copies_after_ingest": n_graph,
                               "roofline": roofline(all_stats, a.steps, world), "breakdown_ms_per_step_summed_over_regions": breakdown(all_stats, a.steps)},
                     "contigs": fasta_out.count(">") if fasta_out else 0}
             line["roofline"] = line["rank0"].pop("roofline")
+            if sat is not None:
+                line["saturating_leg"] = sat
+                line["scaling_model"] = scaling_model(world, work, slowest_alone, sat["min_busy_cus_over_ranks"], n_total)
+                line["scaling_model"]["measured_makespan_s"] = dt / a.steps
+                line["scaling_model"]["note"] = ("the configs[2] set holds 100 regions: sharded over N GPUs every region is in flight at once and the set "
+                                                 "cannot finish before its slowest region has walked its ~1500 dependent levels -- strong scaling on this set is "
+                                                 "capped by that latency, the saturating leg shows what the GPUs sustain")
             print(json.dumps(line), flush=True)
         dist.barrier()
         dist.destroy_process_group()
@@ -322,10 +445,10 @@ def main():
     regions = cli.load_regions(pa)                       # host ingest (rows a1-a4), outside the headline's timed region
     n_graph = sum(sum(r.copies) for _, r in regions)
     params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate), want_timing=True)
-    ctx = capi.Context(local, 1)
+    ctx = make_context(local, 1, resident)
 
-    def step(prepared):
-        texts, stats = stage5.run_regions(ctx, prepared, 1, params)
+    def step(prepared, c=None):
+        texts, stats = stage5.run_regions(c or ctx, prepared, 1, params)
         return "".join(texts), stats
 
     for _ in range(a.warmup):
@@ -347,6 +470,24 @@ def main():
     fence()
     dt_ingest = time.time() - t0
     ctx.close()
+    # the dominant kernel timed with HIP events needs a launch per level: a few steps through the level server
+    launch_stats, launch_ms_per_step = all_stats, None
+    if resident:
+        ctx_l = make_context(local, 1, False)
+        step([(pa, regions)], ctx_l)
+        fence()
+        t1 = time.time()
+        launch_stats = []
+        n_l = min(a.steps, 3)
+        for _ in range(n_l):
+            fa_l, st = step([(pa, regions)], ctx_l)
+            launch_stats += st
+        fence()
+        launch_ms_per_step = 1e3 * (time.time() - t1) / n_l
+        ctx_l.close()
+        assert fa_l == fasta_out, "launch-per-level and resident level workers disagree"
+    rl = roofline(launch_stats, len(launch_stats), 1)
+    rl["resident_level_ms"] = sum(s["sampler_level_ticks"] for s in all_stats) / 1e5 / max(sum(s["sampler_launches"] for s in all_stats), 1)
 
     line = {"metric": "reads/sec into POA (150bp, ~1.5k-node graph)", "value": a.reads * a.steps / dt, "unit": "reads/s",
             "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -355,16 +496,18 @@ def main():
             "config": {"workload": "configs[1]: %d x 150bp reads vs one %dbp gene, %d strains, seed 21, rambl.py options (%s)" % (
                 a.reads, a.glen, a.strains, RAMBL_OPTS),
                 "regions_per_gpu": 1, "regions_in_flight_per_gpu": 1, "parallelism": "one region, one GPU (a single region does not shard: replicas only)",
-                "input_reads": a.reads, "read_copies_after_ingest": n_graph},
-            "roofline": roofline(all_stats, a.steps, 1),
+                "level_execution": mode, "input_reads": a.reads, "read_copies_after_ingest": n_graph},
+            "roofline": rl,
             "breakdown_ms_per_step": breakdown(all_stats, a.steps),
             "contigs": fasta_out.count(">") if fasta_out else 0,
             "with_ingest_matches": with_ingest == fasta_out}
+    if launch_ms_per_step is not None:
+        line["ms_per_step_launch_per_level"] = launch_ms_per_step
     if not a.no_cpu:
         cb, cargs = cpu_baseline(d, fasta, sam, "gene21:%s" % a.sample_roi)
         ref_fa = cb.pop("fasta")
         # the same sample on the GPU (ingest inside the clock, as the CPU figure has it): the like-for-like ratio
-        ctx2 = capi.Context(local, 1)
+        ctx2 = make_context(local, 1, resident)
         pa2 = cli.parse_cmd_line(cargs)
         stage5.run_regions(ctx2, [(pa2, cli.load_regions(pa2))], 1)
         t1 = time.time()
@@ -378,24 +521,49 @@ def main():
         cb["gpu_over_cpu_same_sample_all_cores"] = cb["gpu_same_sample_reads_per_s"] / cb["all_cores"]["value"]
         cb["comparison"] = "the same sample on both sides, ingest included on both: gpu_same_sample_reads_per_s vs value (1 core) and vs all_cores.value"
         line["cpu_baseline"] = cb
+    set_leg = None
     if not a.no_set:
-        # the production shape (rambl.py stage 5 hands over one region per seed gene): the configs[2] set on this GPU with many
-        # regions in flight -- the N = 1 point of the sharded series that `--gpus N` runs; reported beside the headline, not as it
+        # the production shape (rambl.py stage 5 hands over one region per seed gene): the configs[2] set on this GPU with every
+        # region in flight -- the N = 1 point of the sharded series that `--gpus N` runs; reported beside the headline, not as it
         ds = os.path.join(d, "set")
         os.makedirs(ds, exist_ok=True)
         rois, mine, prepared, ingest_s, n_in, n_graph_set, n_total = region_set(ds)
         streams = min(a.streams, len(mine))
-        ctxs = capi.Context(local, streams)
+        ctxs = make_context(local, streams, resident)
         stage5.run_regions(ctxs, prepared[:streams], streams)
+        big = max(range(len(prepared)), key=lambda i: sum(sum(r.copies) for _, r in prepared[i][1]))
+        t1 = time.time()
+        stage5.run_regions(ctxs, [prepared[big]], 1)
+        slowest_alone = time.time() - t1
         t1 = time.time()
         texts, st_set = stage5.run_regions(ctxs, prepared, streams)
         dts = time.time() - t1
         ctxs.close()
-        line["regions_in_flight"] = {"workload": "configs[2] set on one GPU: 100 regions, %d alignments" % n_total, "regions": len(rois),
-                                     "in_flight": streams, "value": n_total / dts, "unit": "reads/s", "seconds": dts,
-                                     "ingest_seconds": ingest_s, "value_with_ingest": n_total / (dts + ingest_s),
-                                     "read_copies_after_ingest": n_graph_set, "contigs": "".join(texts).count(">"),
-                                     "avg_sampler_level_ms": sum(s["chain_wall_ticks"] for s in st_set) / 1e5 / max(sum(s["sampler_launches"] for s in st_set), 1)}
+        set_leg = {"workload": "configs[2] set on one GPU: 100 regions, %d alignments" % n_total, "regions": len(rois),
+                   "in_flight": streams, "value": n_total / dts, "unit": "reads/s", "seconds": dts,
+                   "ingest_seconds": ingest_s, "value_with_ingest": n_total / (dts + ingest_s),
+                   "read_copies_after_ingest": n_graph_set, "contigs": "".join(texts).count(">"),
+                   "slowest_region_alone_s": slowest_alone, "work_level_kernel_seconds": sum(s["level_kernel_ticks"] for s in st_set) / 1e5 / 1e3,
+                   "cu_busy_frac": sum(s["level_kernel_ticks"] for s in st_set) / 1e5 / 1e3 / dts / N_CU,
+                   "avg_sampler_level_ms": sum(s["chain_wall_ticks"] for s in st_set) / 1e5 / max(sum(s["sampler_launches"] for s in st_set), 1)}
+        line["regions_in_flight"] = set_leg
+    if not a.no_saturation:
+        # how many regions in flight fill the GPU, and what it then sustains: regions of the headline's shape (configs[1]
+        # generator, seeds 1000 ...), slots x rounds of them through a context with that many slots
+        dsat = os.path.join(d, "sat")
+        os.makedirs(dsat, exist_ok=True)
+        base = shape_regions(dsat, a.sat_distinct, 1000, a.reads, a.glen, a.strains)
+        pts = [run_in_flight(local, base, int(x), a.sat_rounds, resident, a.reads) for x in a.sat_points.split(",") if int(x) >= 1]
+        best = max(pts, key=lambda q: q["reads_per_s"])
+        line["saturation"] = {"workload": "regions of the configs[1] shape (%d x 150bp reads, %d distinct data sets reused cyclically), in_flight x %d regions per point" % (
+                                  a.reads, a.sat_distinct, a.sat_rounds),
+                              "level_execution": mode, "points": pts, "plateau_reads_per_s": best["reads_per_s"],
+                              "plateau_in_flight": best["in_flight"], "cu_busy_frac_at_plateau": best["cu_busy_frac"],
+                              "definition": "cu_busy_frac = sum over regions of the time inside level kernels / (256 CUs x wall time): a level workgroup holds one CU"}
+        if set_leg is not None:
+            line["scaling_model"] = scaling_model(1, set_leg["work_level_kernel_seconds"], set_leg["slowest_region_alone_s"], best["busy_cus"], n_total)
+            line["scaling_model"]["measured_makespan_s_one_gpu"] = set_leg["seconds"]
+            line["scaling_model"]["workload"] = "the configs[2] set (what `--gpus N` shards): value = its alignments / predicted makespan"
     if not a.no_depth:
         line["hbm_bound_kernel"] = depth_scan_leg(local)
     print(json.dumps(line), flush=True)

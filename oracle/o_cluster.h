@@ -517,10 +517,15 @@ static void streaming_clustering(ClusterCtx *cx, StrainVec *strains_out, int n, 
                 if (nout > 1 + dd) branching = 1;
                 free(oc);
             }
-            if (sub_strains.n > 80) {
+            /* the reference's literal is 80 (NonparametricClustering.cpp:532-551); SC_ORACLE_MAX_CANDIDATES lets a test
+             * raise it (sc_params.max_candidates of the product) so that levels with up to 128 candidates -- the widest
+             * variants of the sampler kernel -- have an oracle too */
+            static int cap80 = 0;
+            if (!cap80) { const char *e = getenv("SC_ORACLE_MAX_CANDIDATES"); cap80 = e ? atoi(e) : 80; if (cap80 < 1) cap80 = 80; }
+            if (sub_strains.n > cap80) {
                 ld *ssa = (ld *)xmalloc(sizeof(ld) * (size_t)sub_strains.n);
                 for (int s = 0; s < sub_strains.n; s++) ssa[s] = sub_strains.v[s].abundance;
-                ld Zt0 = Qx(ssa, sub_strains.n, 80);
+                ld Zt0 = Qx(ssa, sub_strains.n, cap80);
                 int w = 0;
                 for (int s = 0; s < sub_strains.n; s++) {
                     if (sub_strains.v[s].abundance < Zt0) strain_free(&sub_strains.v[s]);

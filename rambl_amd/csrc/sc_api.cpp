@@ -532,9 +532,11 @@ void Ctx::serve_levels() {
             if (resident)
                 for (size_t i = 0; i < flying.size();) {
                     Worker* w = flying[i];
-                    if (w->cur_stream >= 0 || __atomic_load_n(&mail_h[w->slot].state, __ATOMIC_ACQUIRE) != 2u || stamped(w)) { ++i; continue; }
+                    const unsigned ms = __atomic_load_n(&mail_h[w->slot].state, __ATOMIC_ACQUIRE);
+                    if (w->cur_stream >= 0 || ms < 2u || stamped(w)) { ++i; continue; }
                     flying[i] = flying.back(); flying.pop_back();
-                    finish(w, 3, "the slot's resident level worker has left before the level was done");
+                    finish(w, 3, ms == 3u ? "the slot's resident level worker received an item that was not its own"
+                                          : "the slot's resident level worker has left before the level was done");
                 }
             if (!dead.empty()) {
                 for (Worker* w : flying) { if (w->cur_stream >= 0) lstreams[(size_t)w->cur_stream].busy = 0; w->cur_stream = -1; finish(w, 3, dead); }
@@ -560,7 +562,7 @@ void Ctx::resident_ensure(Worker* w) {
         {
             std::lock_guard<std::mutex> lk(gen_mu);
             if (gen_state == GEN_RUNNING) {
-                if (__atomic_load_n(&mail_h[w->slot].state, __ATOMIC_ACQUIRE) != 2u) return;
+                if (__atomic_load_n(&mail_h[w->slot].state, __ATOMIC_ACQUIRE) < 2u) return;
                 // the slot's workgroup has left although regions are in flight (the heartbeat limit): end this generation
                 __atomic_store_n(&ctl_h->stop, 1u, __ATOMIC_RELEASE);
                 gen_state = GEN_STOPPING;
@@ -575,7 +577,7 @@ void Ctx::resident_ensure(Worker* w) {
                 // a workgroup starts from the last stamp its slot has completed: what is in the mailbox beyond that is new
                 for (int i = 0; i < res_slots; i++) { mail_h[i].ack = __atomic_load_n(&workers[(size_t)i]->Rh->seq, __ATOMIC_ACQUIRE); mail_h[i].state = 0; }
                 __atomic_thread_fence(__ATOMIC_RELEASE);
-                ResidentArgs ra{mail_d, ctl_d, 300000000ull};                 // 3 s of 100 MHz ticks without a heartbeat
+                ResidentArgs ra{mail_d, ctl_d, 300000000ull, workers[0]->Pm, workers[0]->Rd};     // 3 s of 100 MHz ticks without a heartbeat
                 (void)hipGetLastError();
                 launch_resident(rstream, ra, res_slots);
                 const hipError_t le = hipGetLastError();
@@ -899,6 +901,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
 
     // ---- level walk: from here on the region's host work is a few microseconds per level
     if (setup_held) { ctx->setup_leave(); setup_held = false; }
+    job.stats.setup_ms = now_ms() - t_cluster0;
     std::vector<HStrain> level_strains, sub_strains;
     std::vector<Model> models;                                           // pool; free entries in free_models
     std::vector<int> free_models;
@@ -1041,7 +1044,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 unsigned spins = 0;
                 while (__atomic_load_n(&Rh->seq, __ATOMIC_ACQUIRE) != H.seq) {
                     __builtin_ia32_pause();
-                    if ((++spins & 0xFFFFFu) == 0 && __atomic_load_n(&mb.state, __ATOMIC_ACQUIRE) == 2u &&
+                    if ((++spins & 0xFFFFFu) == 0 && __atomic_load_n(&mb.state, __ATOMIC_ACQUIRE) >= 2u &&
                         __atomic_load_n(&Rh->seq, __ATOMIC_ACQUIRE) != H.seq)
                         throw HipError("the resident level worker has left before the level was done");
                 }
@@ -1095,6 +1098,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             t_last_done = t_done;
         }
         job.stats.xcd_levels[Rh->xcc & 7]++;
+        job.stats.kind_levels[std::min(std::max(level_kind(H), 0), 16)]++;
     };
 
     for (int level = 0; level < f.n_levels; level++) {

@@ -102,7 +102,7 @@ struct alignas(128) Mailbox {
     LevelItem item;              // the level to run
     unsigned seq;                // host: LevelHdr::seq of `item`, stored last
     unsigned ack;                // host: the slot's last stamp before this generation of the grid was launched
-    unsigned state;              // kernel: 1 resident, 2 gone
+    unsigned state;              // kernel: 1 resident, 2 gone, 3 gone after an item that did not name this slot's blocks
     unsigned levels;             // kernel: levels served by this generation (diagnostics)
     unsigned pad[8];
 };
@@ -112,10 +112,14 @@ struct ResidentCtl {
     unsigned heartbeat;          // host: keeps changing while the context's server thread is alive
     unsigned pad[30];
 };
+struct LevelParams;
+struct LevelResult;
 struct ResidentArgs {
     Mailbox* mail;               // host-mapped, [slots]
     const ResidentCtl* ctl;      // host-mapped
     unsigned long long idle_ticks;   // 100 MHz ticks without a heartbeat change after which a workgroup gives up
+    const LevelParams* P_base;   // the slots' host-mapped parameter / result blocks: slot b's item must name block b
+    LevelResult* R_base;
 };
 
 // Per-level results, written by the kernel into host-mapped pinned memory; `seq` last (system-scope release).

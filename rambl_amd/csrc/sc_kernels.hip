@@ -1102,17 +1102,19 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_level_resident(ResidentArgs a
                 for (int i = 0; i < 5; i++) dst[i] = src[i];
                 last = s_item.h.seq;
                 served++;
+                // an item that does not name this slot's own blocks was not written for it: leave rather than follow its pointers
+                if (s_item.P != a.P_base + blockIdx.x || s_item.R != a.R_base + blockIdx.x || s_item.job == nullptr) cmd = 2;
             }
             s_cmd = cmd;
         }
         __syncthreads();
-        if (!s_cmd) break;
+        if (s_cmd != 1) break;
         level_dispatch(&s_item);
         __syncthreads();                                   // the level is stamped; s_item and s_cmd may be rewritten
     }
     if (tid == 0) {
         __hip_atomic_store(&mb->levels, served, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&mb->state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mb->state, s_cmd == 2 ? 3u : 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 // --------------------------------------------------------------------------

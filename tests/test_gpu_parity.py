@@ -506,3 +506,54 @@ def test_region_from_bam_matches_oracle(seed, tmp_path, oracle_bin, monkeypatch)
     bam = os.path.join(d, "reads.bam")
     T.write_bam(args[-1], bam)
     assert T.run_product(args[:-1] + [bam]) == exp_fa
+
+
+def test_msa_kernel_on_the_reference_vectors():
+    """k_msa against the reference itself, with nothing in between: every case of tests/golden/msa_vectors.json.gz (rows
+    printed by the reference's own MultipleSequenceAlignmentSP::align through oracle/_ref/msa_ref in the build
+    container, MultipleSequenceAlignmentSP.cpp:10-301)."""
+    import gzip
+    import json
+    from rambl_amd import capi
+    cases = json.loads(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "msa_vectors.json.gz")).read())
+    assert len(cases) >= 100
+    with capi.Context(0, 1) as ctx:
+        for c in cases:
+            rows = ctx.msa_align(c["seqs"])
+            assert rows == c["rows"], c["seqs"]
+            assert len(rows[0]) == c["ncol"]
+
+
+def test_every_wide_sampler_variant_is_exercised(tmp_path):
+    """The sampler kernel has one variant per 16 candidates (NB = 1..8) and per home of the weight rows (LDS / HBM).  Under
+    the reference's cap of 80 candidates (NonparametricClustering.cpp:532-551) the 50-strain region of config4_deep reaches
+    NB = 6; with the cap raised to 120 (sc_params.max_candidates; SC_ORACLE_MAX_CANDIDATES for the oracle, whose stdout is
+    tests/golden/config4_deep_cap120) levels with up to 128 candidates run NB = 7 and 8 too.  The histogram of sc_stats
+    says which variants served the levels: none of NB = 5..8 may go unexercised, and the FASTA must equal the fixtures."""
+    import hashlib
+    import json
+    from rambl_amd import capi, cli, synth
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(gold, "config4_deep", "meta.json")))
+    gene = synth.make_gene(4, glen=1500, n_strains=50, n_reads=100000, name="deep4")
+    fa, sam = synth.write_dataset(str(tmp_path), [gene])
+    assert hashlib.sha256(open(sam, "rb").read()).hexdigest() == meta["sam_sha256"]
+    pa = cli.parse_cmd_line(meta["argv"] + [fa, sam])
+    regions = cli.load_regions(pa)
+    hist = [0] * 17
+    with capi.Context(0, 2) as ctx:
+        hs = []
+        for cap in (80, 120):
+            params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate))
+            params.max_candidates = cap
+            hs.append([(w, ctx.submit(r, params)) for w, r in regions])
+        for cap, handles, name in ((80, hs[0], "config4_deep"), (120, hs[1], "config4_deep_cap120")):
+            text = ""
+            for w, h in handles:
+                res = ctx.wait(h)
+                text += cli.format_fasta(w, res, pa.tau)
+                hist = [a + b for a, b in zip(hist, res.stats["kind_levels"])]
+            assert text == open(os.path.join(gold, name, "expected.fa")).read(), name
+    by_nb = {nb: hist[1 + 2 * (nb - 1)] + hist[2 + 2 * (nb - 1)] for nb in range(1, 9)}
+    assert all(by_nb[nb] > 0 for nb in (5, 6, 7, 8)), by_nb
+    assert sum(hist) > 2000

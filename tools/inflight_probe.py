@@ -83,7 +83,8 @@ def main():
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
         rec["cpu_cores_used"] = round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / dt, 2)
         rec["t_end"] = t_end
-        rec["gap_us_per_level"] = round(1e3 * (rec["cluster_ms"] - rec["level_kernel_ms"]) / max(rec["levels"], 1), 1)
+        rec["setup_ms"] = round(sum(s["setup_ms"] for s in stats) / n, 1)
+        rec["gap_us_per_level"] = round(1e3 * (rec["cluster_ms"] - rec["setup_ms"] - rec["level_kernel_ms"]) / max(rec["levels"], 1), 1)
         # share of the GPU's 256 CUs that held a level workgroup, averaged over the run
         rec["cu_busy_frac"] = round(sum(s["level_kernel_ticks"] for s in stats) / 1e5 / 1e3 / (256 * dt), 3)
         print(json.dumps(rec), flush=True)
