@@ -263,7 +263,8 @@ def test_stage5_many_regions_one_gpu(tmp_path, oracle_bin):
 def test_thread_kernels_class_tables(seed, tmp_path):
     """k_thread_* (row a5) against a plain restatement of the per-base M loop
     (PartialOrderGraph.cpp:129-177): class sizes, first read per class, pools in read order."""
-    from rambl_amd import capi, cli, ingest
+    import py_ingest_mirror as mirror
+    from rambl_amd import capi, cli
     args = T.make_case(seed, str(tmp_path))
     pa = cli.parse_cmd_line(args)
     params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate), graph_only=True)
@@ -280,7 +281,7 @@ def test_thread_kernels_class_tables(seed, tmp_path):
             exp = {}
             for rid in range(len(reads)):
                 i, j = reads.pos[rid], 0
-                for op, ln in ingest.parse_cigar(reads.cigar[rid]):
+                for op, ln in mirror.parse_cigar(reads.cigar[rid]):
                     if op == "M":
                         for t in range(ln):
                             exp.setdefault((i + t) * 8 + code[ord(reads.seq[rid][j + t])], []).append(rid)
@@ -499,7 +500,6 @@ def test_config4_million_reads_unthinned_matches_oracle(million_reads):
 def test_region_from_bam_matches_oracle(seed, tmp_path, oracle_bin, monkeypatch):
     """BAM in (read by the library's own BGZF / BAM decoder: no samtools in the image), FASTA out: equal to the oracle
     on the SAM text the BAM was written from (paired reads; several scan windows)."""
-    monkeypatch.setenv("SC_NATIVE_BAM", "1")
     d = str(tmp_path)
     args = T.make_case(seed, d)
     exp_fa, _ = T.run_oracle(args, d)

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import sc_testlib as T
+import py_ingest_mirror as mirror          # the Python restatement of the read path (test infrastructure)
 from rambl_amd import cli, ingest
 
 ROOT = T.ROOT
@@ -108,10 +109,10 @@ def test_mt19937_canonical_stream(oracle_bin):
     n = 3000
     out = (ctypes.c_double * n)()
     lib.oracle_mt_canonical(1234, n, out)
-    gen = ingest.MT19937(1234)
+    gen = mirror.MT19937(1234)
     assert [gen.canonical() for _ in range(n)] == list(out)
     # std::mt19937 known answer: the 10000th output of the default-seeded engine is 4123659995
-    g = ingest.MT19937(5489)
+    g = mirror.MT19937(5489)
     v = 0
     for _ in range(10000):
         v = g.next_u32()
@@ -144,11 +145,11 @@ def test_cli_help_goes_to_stderr():
 
 
 def test_crop_and_cigar_helpers():
-    assert ingest.parse_cigar("3S10M2I4D5=6X") == [("S", 3), ("M", 10), ("I", 2), ("D", 4), ("M", 5), ("M", 6)]
-    cig = ingest.parse_cigar("10M")
-    assert ingest.crop_read_within_window(5, 8, "ACGTACGTAC", "IIIIIIIIII", cig, 3, 12) == ("GTAC", "4M")
-    assert ingest.crop_read_within_window(1, 100, "ACGTACGTAC", "IIIIIIIIII", cig, 3, 12) == ("ACGTACGTAC", "10M")
-    assert ingest.max_insert_size("5M3I2M7I1M") == 7
+    assert mirror.parse_cigar("3S10M2I4D5=6X") == [("S", 3), ("M", 10), ("I", 2), ("D", 4), ("M", 5), ("M", 6)]
+    cig = mirror.parse_cigar("10M")
+    assert mirror.crop_read_within_window(5, 8, "ACGTACGTAC", "IIIIIIIIII", cig, 3, 12) == ("GTAC", "4M")
+    assert mirror.crop_read_within_window(1, 100, "ACGTACGTAC", "IIIIIIIIII", cig, 3, 12) == ("ACGTACGTAC", "10M")
+    assert mirror.max_insert_size("5M3I2M7I1M") == 7
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 5, 6, 13])
@@ -157,16 +158,16 @@ def test_pileup_flags_equal_pileup_text(seed, tmp_path):
     from rambl_amd import samio
     args = T.make_case(seed, str(tmp_path))
     aln = samio.Alignments(args[-1])
+    text = mirror.SamText(args[-1])
     name = "g%d" % seed
     for region in ("%s:1-5000" % name, "%s:40-180" % name, "%s:200-260" % name):
         for mq in (0, 50):
-            assert aln.pileup_flags(mq, region) == samio.flags_from_pileup_text(aln.mpileup(mq, region))
+            assert aln.pileup_flags(mq, region) == mirror.flags_from_pileup_text(text.mpileup(mq, region)) == text.pileup_flags(mq, region)
 
 
 @pytest.mark.parametrize("seed", [2, 4])
 def test_native_bam_reader_gives_the_same_regions(seed, tmp_path, monkeypatch):
     """BAM input read natively (no samtools in the image) yields the same ingest as the SAM text."""
-    monkeypatch.setenv("SC_NATIVE_BAM", "1")
     d = str(tmp_path)
     args = T.make_case(seed, d)
     bam = os.path.join(d, "reads.bam")
@@ -241,7 +242,7 @@ def test_native_ingest_equals_python_mirror(seed, tmp_path):
     sam = str(tmp_path / "x.sam")
     _random_sam(rng, sam)
     nat = capi.NativeAln(sam)
-    py = samio.SamText(sam)
+    py = mirror.SamText(sam)
 
     class PyAln:
         native = None
@@ -258,7 +259,7 @@ def test_native_ingest_equals_python_mirror(seed, tmp_path):
         roi = "%s:%d-%d" % (g, p0, p1)
         assert nat.pileup_flags(mq, g, p0, p1) == py.pileup_flags(mq, roi)
         try:
-            exp = ingest.load_mapping_reads("", PyAln, mq, rl, max_ins, max_depth, roi)
+            exp = mirror.load_mapping_reads("", PyAln, mq, rl, max_ins, max_depth, roi)
         except (ValueError, IndexError):
             with pytest.raises(capi.StrainCallError):
                 nat.load_reads("", g, p0, p1, mq, rl, max_ins, max_depth)
@@ -362,7 +363,7 @@ def test_bam_decoder_on_hand_assembled_bytes(tmp_path):
         ["r3", "73", "otuB", "1", "255", "7M", "=", "1", "0", "ACGTNRY", "!\"#$%&'"],
         ["r4", "77", "*", "0", "0", "*", "*", "0", "0", "TTTT", "????"],
     ]
-    assert list(samio.bam_records(path)) == expected
+    assert list(mirror.bam_records(path)) == expected
     aln = capi.NativeAln(path)
     assert aln.records() == 4
     assert aln.ref_stats("otuA") == (2, (3 + 1 + 1 + 2) + (5 + 4 + 3)) and aln.ref_stats("otuB") == (1, 7) and aln.ref_stats("*") == (1, 1)
@@ -389,8 +390,8 @@ def test_reference_skip_is_coverage_not_deletion(tmp_path):
     want = {p: (False, p in (15, 16)) for p in list(range(5, 19)) + list(range(20, 28))}     # 15: "-1N" on the base before; 16: '*'
     nat = capi.NativeAln(str(sam))
     assert nat.pileup_flags(0, "g", 1, 60) == want
-    text = samio.SamText(str(sam))
+    text = mirror.SamText(str(sam))
     assert text.pileup_flags(0, "g:1-60") == want
     lines = text.mpileup(0, "g:1-60")
-    assert samio.flags_from_pileup_text(lines) == want
+    assert mirror.flags_from_pileup_text(lines) == want
     assert ">" in lines[4].split("\t")[4] and "<" in [ln for ln in lines if ln.split("\t")[1] == "23"][0].split("\t")[4]
