@@ -79,6 +79,8 @@ typedef struct sc_stats {
     int n_nodes, n_levels, n_unique_reads;
     long n_read_copies;
     double setup_ms;          /* the part of cluster_ms before the first level: uploads of the level-major arrays, edge support */
+    double queue_ms;          /* from sc_roi_submit until a slot took the region */
+    double place_ms;          /* the part of graph_ms spent waiting for one of the context's set-up places */
     long kind_levels[17];     /* levels served by each variant of the level kernel: [0] no sampler (k_level); [1 + 2 * (NB - 1) + L]
                                * the sampler for NB = ceil(candidates / 16) register blocks, L = 1 weight rows in LDS, 0 in HBM */
 } sc_stats;

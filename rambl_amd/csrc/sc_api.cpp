@@ -175,6 +175,7 @@ struct Job {
     std::vector<int> thr_count, thr_first, thr_pool;
     std::string thr_sym;
     sc_stats stats{};
+    double t_submit = 0;
     int status = 0;       // 0 queued/running, 1 done
     int rc = SC_OK;
     std::string err;
@@ -329,6 +330,7 @@ struct Worker {
     unsigned level_want = 0;          // stamp of that level
     int cur_stream = -1;              // its launch stream (server's bookkeeping)
     std::string level_err;
+    double t_posted = 0;              // when the level went into the slot's mailbox (resident workers)
     double t_batch_launched = 0;      // diagnostics: when the level's batch was launched, and its size
     int batch_n = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;     // the pair of the level being launched (from ev_pool when timing)
@@ -392,6 +394,9 @@ void Worker::sync_stream() {
         // a set-up stream that makes no progress for minutes is stuck (e.g. queued behind something that waits for this
         // region): an error for this region, not a hang of the process
         if ((spins & 0x3FFu) == 0x3FFu && now_ms() - t0 > 180000.0) throw HipError("set-up stream: no progress for 3 minutes");
+        // the copies / kernels waited for take from 0.1 to a few milliseconds: while nothing else is ready, this thread sleeps a
+        // little instead of going round the scheduler (its lock is the one the level server makes regions ready under)
+        if (ctx->pool->ready_now() == 0) std::this_thread::sleep_for(std::chrono::microseconds(40));
         FiberPool::yield();
     }
 }
@@ -435,7 +440,23 @@ void Ctx::serve_levels() {
         pool->make_ready(w->fib);
     };
     auto stamped = [](Worker* w) { return __atomic_load_n(&w->Rh->seq, __ATOMIC_ACQUIRE) == w->level_want; };
+    // a resident workgroup that has left (heartbeat limit, or a fault that ended the grid) or never started will not stamp
+    auto check_resident = [&]() {
+        if (!resident) return;
+        for (size_t i = 0; i < flying.size();) {
+            Worker* w = flying[i];
+            const unsigned ms = __atomic_load_n(&mail_h[w->slot].state, __ATOMIC_ACQUIRE);
+            const bool never = ms == 0u && now_ms() - w->t_posted > 20000.0;       // more slots than the GPU holds resident
+            if (w->cur_stream >= 0 || (ms < 2u && !never) || stamped(w)) { ++i; continue; }
+            flying[i] = flying.back(); flying.pop_back();
+            finish(w, 3, never ? "the slot's resident level worker has not started within 20 s (more slots than the GPU holds resident workgroups?)"
+                         : ms == 3u ? "the slot's resident level worker received an item that was not its own"
+                                    : "the slot's resident level worker has left before the level was done");
+        }
+    };
+    unsigned loops = 0;
     unsigned idle_spins = 0;
+    double t_check = now_ms();
     const bool any_kind = !(getenv("SC_ANY_KIND") && atoi(getenv("SC_ANY_KIND")) == 0);
     for (;;) {
         if (n_pending.load(std::memory_order_acquire) > 0 || (waiting.empty() && flying.empty())) {
@@ -449,6 +470,7 @@ void Ctx::serve_levels() {
             }
             n_pending.store(0, std::memory_order_release);
         }
+        if ((++loops & 0xFFFFu) == 0 && resident && now_ms() - t_check > 2000.0) { t_check = now_ms(); check_resident(); }
         bool progressed = false;
         // completions
         for (size_t i = 0; i < flying.size();) {
@@ -528,16 +550,7 @@ void Ctx::serve_levels() {
                     finish(w, 3, "a level kernel ended without its completion stamp");
                 }
             }
-            // a resident workgroup that has left (heartbeat limit, or a fault that ended the grid) will not stamp either
-            if (resident)
-                for (size_t i = 0; i < flying.size();) {
-                    Worker* w = flying[i];
-                    const unsigned ms = __atomic_load_n(&mail_h[w->slot].state, __ATOMIC_ACQUIRE);
-                    if (w->cur_stream >= 0 || ms < 2u || stamped(w)) { ++i; continue; }
-                    flying[i] = flying.back(); flying.pop_back();
-                    finish(w, 3, ms == 3u ? "the slot's resident level worker received an item that was not its own"
-                                          : "the slot's resident level worker has left before the level was done");
-                }
+            check_resident();
             if (!dead.empty()) {
                 for (Worker* w : flying) { if (w->cur_stream >= 0) lstreams[(size_t)w->cur_stream].busy = 0; w->cur_stream = -1; finish(w, 3, dead); }
                 flying.clear();
@@ -1039,14 +1052,17 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             Mailbox& mb = ctx->mail_h[slot];
             mb.item = LevelItem{jd_dev, H, level_kind(H) | (level_lds_kb(H, K) << 8), Pm, Rd};
             __atomic_store_n(&mb.seq, H.seq, __ATOMIC_RELEASE);
-            t_batch_launched = level_log ? now_ms() : 0.0; batch_n = 1;
+            t_posted = now_ms();
+            t_batch_launched = level_log ? t_posted : 0.0; batch_n = 1;
             if (ctx->workers.size() == 1) {
                 unsigned spins = 0;
                 while (__atomic_load_n(&Rh->seq, __ATOMIC_ACQUIRE) != H.seq) {
                     __builtin_ia32_pause();
-                    if ((++spins & 0xFFFFFu) == 0 && __atomic_load_n(&mb.state, __ATOMIC_ACQUIRE) >= 2u &&
-                        __atomic_load_n(&Rh->seq, __ATOMIC_ACQUIRE) != H.seq)
+                    if ((++spins & 0xFFFFFu) != 0) continue;
+                    const unsigned ms = __atomic_load_n(&mb.state, __ATOMIC_ACQUIRE);
+                    if (ms >= 2u && __atomic_load_n(&Rh->seq, __ATOMIC_ACQUIRE) != H.seq)
                         throw HipError("the resident level worker has left before the level was done");
+                    if (ms == 0u && now_ms() - t_posted > 20000.0) throw HipError("the resident level worker has not started within 20 s");
                 }
             } else {
                 ctx->submit_level(LevelRequest{this, LevelItem{}, KIND_POSTED, false});
@@ -1365,8 +1381,10 @@ void Worker::process(Job& job) {
         Worker* w;
         ~Setup() { if (w->setup_held) { w->ctx->setup_leave(); w->setup_held = false; } }
     } setup{this};
+    job.stats.queue_ms = t0 - job.t_submit;
     ctx->setup_enter();
     setup_held = true;
+    job.stats.place_ms = now_ms() - t0;
     stage = ctx->lease_arena(&passthrough);
     MsaFn msa = [this](const std::vector<std::string>& seqs, std::vector<std::string>& rows) { return msa_device(seqs, rows); };
     ThreadFn thr = [this, &job](const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cg,
@@ -1471,7 +1489,10 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         const char* e = getenv("SC_RESIDENT");
         ctx->resident = e ? atoi(e) != 0 : false;
         const char* rs = getenv("SC_RESIDENT_SLOTS");
-        int cap = rs ? atoi(rs) : std::max(prop.multiProcessorCount - 24, 1);
+        // Measured on MI355X: 224 resident workgroups (8 wavefronts each, 1 792 in all) start, the ones beyond do not (232: their
+        // regions wait for ever, or the grid faults) -- the kernel keeps its variants as functions, their stack frames live in
+        // scratch memory, and the queue's scratch holds 7 wavefronts per CU.  32 CUs stay free for the set-up kernels.
+        int cap = rs ? atoi(rs) : std::max(prop.multiProcessorCount - 32, 1);
         cap = cap < 1 ? 1 : (cap > prop.multiProcessorCount ? prop.multiProcessorCount : cap);
         if (ctx->resident && stream_count > cap) stream_count = cap;
         ctx->res_slots = stream_count;
@@ -1634,6 +1655,7 @@ int sc_roi_submit(sc_ctx* h, const char* ref_bases, int ref_len, const int* read
         if (read_copies[i] < 1 || cigar_off[i + 1] < cigar_off[i] || seq_off[i + 1] < seq_off[i] || mate_off[i + 1] < mate_off[i])
             return SC_ERR_ARG;
     auto job = std::make_shared<Job>();
+    job->t_submit = now_ms();
     job->ref.assign(ref_bases, (size_t)ref_len);
     job->reads.resize((size_t)n_reads);
     for (int i = 0; i < n_reads; i++) {

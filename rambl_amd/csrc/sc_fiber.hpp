@@ -10,7 +10,6 @@
 // drives it on the CPU.
 #pragma once
 #include <sys/mman.h>
-#include <ucontext.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -22,12 +21,45 @@
 #include <thread>
 #include <vector>
 
+// The switch itself: callee-saved registers, the SSE and x87 control words (the library computes in long double: the
+// precision control travels with the fiber), the stack pointer.  No signal mask (swapcontext makes two system calls per
+// switch for it; a region switches twice per level).  x86-64 System V.
+extern "C" void sc_fiber_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .weak sc_fiber_switch
+    .type sc_fiber_switch,@function
+sc_fiber_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size sc_fiber_switch,.-sc_fiber_switch
+)");
+
 namespace sc {
 
 class FiberPool;
 
 struct Fiber {
-    ucontext_t ctx{};
+    void* sp = nullptr;                 // saved stack pointer while the fiber is not running
     void* stack = nullptr;
     size_t stack_bytes = 0;
     std::function<void()> body;
@@ -37,7 +69,7 @@ struct Fiber {
     std::atomic<bool> on_cpu{false};
     std::atomic<bool> finished{false};
     FiberPool* pool = nullptr;
-    ucontext_t* back = nullptr;         // the executor context the fiber returns to when it parks
+    void** back = nullptr;              // where the executor that runs the fiber keeps its own stack pointer
 };
 
 class FiberPool {
@@ -65,12 +97,18 @@ public:
         f->stack = p; f->stack_bytes = stack_bytes + page;
         f->body = std::move(body);
         f->pool = this;
-        getcontext(&f->ctx);
-        f->ctx.uc_stack.ss_sp = (char*)p + page;
-        f->ctx.uc_stack.ss_size = stack_bytes;
-        f->ctx.uc_link = nullptr;
-        const uintptr_t v = (uintptr_t)f;
-        makecontext(&f->ctx, (void (*)())&FiberPool::entry, 2, (unsigned)(v & 0xffffffffu), (unsigned)(v >> 32));
+        // the frame sc_fiber_switch pops on the first switch into the fiber: control words, six registers, the address of
+        // entry(); above it a null return address, so that entry() starts on the alignment a call would have left
+        uintptr_t top = ((uintptr_t)p + page + stack_bytes) & ~(uintptr_t)15;
+        uint64_t* w = (uint64_t*)(top - 72);
+        uint32_t mxcsr; uint16_t fpucw;
+        asm volatile("stmxcsr %0" : "=m"(mxcsr));
+        asm volatile("fnstcw %0" : "=m"(fpucw));
+        w[0] = (uint64_t)mxcsr | ((uint64_t)fpucw << 32);
+        for (int i = 1; i <= 6; i++) w[i] = 0;
+        w[7] = (uint64_t)(uintptr_t)&FiberPool::entry;
+        w[8] = 0;
+        f->sp = w;
         { std::lock_guard<std::mutex> lk(mu_); all_.push_back(f); }
         return f;
     }
@@ -85,6 +123,7 @@ public:
             std::lock_guard<std::mutex> lk(mu_);
             (later ? later_ : ready_).push_back(f);
         }
+        if (!later) n_front_.fetch_add(1, std::memory_order_release);
         n_ready_.fetch_add(1, std::memory_order_release);
         if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_one();
     }
@@ -92,14 +131,17 @@ public:
     // From inside a fiber: give the thread back until somebody calls make_ready(this fiber).
     static void park() {
         Fiber* f = current();
-        swapcontext(&f->ctx, f->back);
+        sc_fiber_switch(&f->sp, *f->back);
     }
     // From inside a fiber: let the other ready fibers run first.
     static void yield() {
         Fiber* f = current();
         f->pool->make_ready(f, true);
-        swapcontext(&f->ctx, f->back);
+        sc_fiber_switch(&f->sp, *f->back);
     }
+    // fibers made ready the ordinary way and not taken yet (a fiber that polls for something may sleep instead of yielding
+    // while this is zero)
+    int ready_now() const { return n_front_.load(std::memory_order_acquire); }
     static Fiber*& current() { return tl_current(); }
     static bool in_fiber() { return tl_current() != nullptr; }
 
@@ -129,22 +171,24 @@ private:
         asm volatile("" ::: "memory");
         return cur;
     }
-    static void entry(unsigned lo, unsigned hi) {
-        Fiber* f = (Fiber*)((uintptr_t)lo | ((uintptr_t)hi << 32));
+    static void entry() {
+        Fiber* f = tl_current();
         f->body();
         f->finished.store(true, std::memory_order_release);
-        // back to the executor for good (re-read the executor context: the fiber may have migrated since it started)
-        setcontext(f->back);
+        // back to the executor for good (the executor of NOW: the fiber may have migrated since it started)
+        f = tl_current();
+        sc_fiber_switch(&f->sp, *f->back);
+        __builtin_trap();
     }
     void run() {
         if (on_start_) on_start_();
-        ucontext_t self{};
+        void* self_sp = nullptr;
         unsigned spins = 0;
         for (;;) {
             Fiber* f = nullptr;
             if (n_ready_.load(std::memory_order_acquire) > 0) {
                 std::lock_guard<std::mutex> lk(mu_);
-                if (!ready_.empty()) { f = ready_.front(); ready_.pop_front(); n_ready_.fetch_sub(1, std::memory_order_relaxed); }
+                if (!ready_.empty()) { f = ready_.front(); ready_.pop_front(); n_ready_.fetch_sub(1, std::memory_order_relaxed); n_front_.fetch_sub(1, std::memory_order_relaxed); }
                 else if (!later_.empty()) { f = later_.front(); later_.pop_front(); n_ready_.fetch_sub(1, std::memory_order_relaxed); }
             }
             if (!f) {
@@ -166,9 +210,9 @@ private:
             const int r = running_.fetch_add(1, std::memory_order_relaxed) + 1;
             int m = max_running_.load(std::memory_order_relaxed);
             while (r > m && !max_running_.compare_exchange_weak(m, r, std::memory_order_relaxed)) {}
-            f->back = &self;
+            f->back = &self_sp;
             tl_current() = f;
-            swapcontext(&self, &f->ctx);
+            sc_fiber_switch(&self_sp, f->sp);
             tl_current() = nullptr;
             running_.fetch_sub(1, std::memory_order_relaxed);
             switches_.fetch_add(1, std::memory_order_relaxed);
@@ -182,7 +226,7 @@ private:
     std::condition_variable cv_;
     std::deque<Fiber*> ready_, later_;
     std::vector<Fiber*> all_;
-    std::atomic<int> n_ready_{0}, sleepers_{0}, running_{0}, max_running_{0};
+    std::atomic<int> n_ready_{0}, n_front_{0}, sleepers_{0}, running_{0}, max_running_{0};
     std::atomic<long> switches_{0};
     bool stop_ = false;
 };

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -58,6 +59,8 @@ int main(int argc, char** argv) {
             r->f = pool.create([&, r, i] {
                 double local[64];                                  // lives on the fiber's stack across every park
                 for (int k = 0; k < 64; k++) local[k] = i + k;
+                long double ext = 0;
+                int caught = 0;
                 for (int lv = 0; lv < L; lv++) {
                     r->state.store(1, std::memory_order_release);
                     { std::lock_guard<std::mutex> lk(mu); posted.push_back(r); }
@@ -67,9 +70,19 @@ int main(int argc, char** argv) {
                     if (r->state.load(std::memory_order_acquire) != 2) { r->levels_done = -1000000; break; }
                     local[lv & 63] += 1.0;
                     r->levels_done++;
+                    // long double bookkeeping and a C++ exception thrown and caught inside the fiber, wherever it runs by now
+                    ext += 1.0L / 3.0L;
+                    if ((lv & 127) == 5) {
+                        try { throw std::runtime_error("x"); } catch (const std::runtime_error&) { caught++; }
+                    }
                     if ((lv & 31) == 0) FiberPool::yield();
                 }
                 for (int k = 0; k < 64; k++) r->acc += local[k];
+                long double want = 0;
+                for (int lv = 0; lv < L; lv++) want += 1.0L / 3.0L;
+                int want_caught = 0;
+                for (int lv = 0; lv < L; lv++) want_caught += (lv & 127) == 5;
+                if (ext != want || caught != want_caught) r->levels_done = -1;       // (80-bit sums: the x87 control word came along)
                 finished.fetch_add(1);
             }, 256 * 1024);
             pool.make_ready(r->f);

@@ -54,7 +54,11 @@ def main():
     distinct = int(os.environ.get("SC_PROBE_DISTINCT", "48"))
     rounds = int(os.environ.get("SC_PROBE_ROUNDS", "1"))
     base = prepare(min(max(rs), distinct), reads)
-    for r in rs:
+    # SC_PROBE_SWEEP="SC_SETUP_LIMIT=4,SC_EXEC_THREADS=8;SC_SETUP_LIMIT=16": every R once per setting (the library reads
+    # these when a context is created)
+    sweep = [dict(kv.split("=") for kv in part.split(",") if kv) for part in os.environ.get("SC_PROBE_SWEEP", "").split(";")] or [{}]
+    for r, knobs in [(r, k) for r in rs for k in sweep]:
+        os.environ.update(knobs)
         prep = [base[i % len(base)] for i in range(r * rounds)]
         ctx = capi.Context(0, r)
         params = capi.default_params(0.01, 0.02, 0.02)
@@ -84,6 +88,9 @@ def main():
         rec["cpu_cores_used"] = round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / dt, 2)
         rec["t_end"] = t_end
         rec["setup_ms"] = round(sum(s["setup_ms"] for s in stats) / n, 1)
+        rec["queue_ms"] = round(sum(s["queue_ms"] for s in stats) / n, 1)
+        rec["place_ms"] = round(sum(s["place_ms"] for s in stats) / n, 1)
+        rec["knobs"] = {k: os.environ[k] for k in ("SC_EXEC_THREADS", "SC_SETUP_LIMIT", "SC_RESIDENT_SLOTS") if k in os.environ}
         rec["gap_us_per_level"] = round(1e3 * (rec["cluster_ms"] - rec["setup_ms"] - rec["level_kernel_ms"]) / max(rec["levels"], 1), 1)
         # share of the GPU's 256 CUs that held a level workgroup, averaged over the run
         rec["cu_busy_frac"] = round(sum(s["level_kernel_ticks"] for s in stats) / 1e5 / 1e3 / (256 * dt), 3)
