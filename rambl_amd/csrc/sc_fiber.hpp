@@ -78,6 +78,7 @@ public:
     explicit FiberPool(int n_threads, std::function<void()> on_thread_start = nullptr)
         : on_start_(std::move(on_thread_start)) {
         if (n_threads < 1) n_threads = 1;
+        if (const char* e = getenv("SC_EXEC_SPINNERS")) max_spinners_ = atoi(e) < 0 ? 0 : atoi(e);
         for (int i = 0; i < n_threads; i++) threads_.emplace_back([this] { run(); });
     }
     ~FiberPool() { shutdown(); }
@@ -124,8 +125,10 @@ public:
             (later ? later_ : ready_).push_back(f);
         }
         if (!later) n_front_.fetch_add(1, std::memory_order_release);
-        n_ready_.fetch_add(1, std::memory_order_release);
-        if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_one();
+        const int nr = n_ready_.fetch_add(1, std::memory_order_release) + 1;
+        // a spinning executor sees the counter at once; a sleeping one is woken only when no spinner is there to take this
+        // fiber (a futex call per level would cost the level server more than the level's own bookkeeping)
+        if (sleepers_.load(std::memory_order_acquire) > 0 && nr > spinners_.load(std::memory_order_acquire)) cv_.notify_one();
     }
 
     // From inside a fiber: give the thread back until somebody calls make_ready(this fiber).
@@ -192,19 +195,27 @@ private:
                 else if (!later_.empty()) { f = later_.front(); later_.pop_front(); n_ready_.fetch_sub(1, std::memory_order_relaxed); }
             }
             if (!f) {
-                // nothing ready: spin briefly (a level lasts ~0.5 ms, completions arrive all the time under load), then sleep
-                if (++spins < 2000) { __builtin_ia32_pause(); continue; }
+                // Nothing ready.  A rank's CPU share is a quota of CPU TIME (a GPU box hands out 16 CPUs of its host as a cgroup
+                // bandwidth limit): an executor that spins spends the quota the regions' bookkeeping needs.  So at most
+                // `max_spinners_` executors wait by spinning (they pick a level's continuation up within a fraction of a
+                // microsecond); the others sleep and are woken when fibers queue up behind the spinners.
+                if (spinners_.load(std::memory_order_acquire) < max_spinners_) {
+                    spinners_.fetch_add(1, std::memory_order_acq_rel);
+                    for (spins = 0; spins < 6000 && n_ready_.load(std::memory_order_acquire) == 0; spins++) __builtin_ia32_pause();
+                    spinners_.fetch_sub(1, std::memory_order_acq_rel);
+                    if (n_ready_.load(std::memory_order_acquire) > 0) continue;
+                }
                 std::unique_lock<std::mutex> lk(mu_);
                 if (stop_ && ready_.empty() && later_.empty()) return;
                 if (ready_.empty() && later_.empty()) {
                     sleepers_.fetch_add(1, std::memory_order_release);
-                    cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return stop_ || !ready_.empty() || !later_.empty(); });
+                    cv_.wait_for(lk, std::chrono::milliseconds(20), [&] { return stop_ || !ready_.empty() || !later_.empty(); });
                     sleepers_.fetch_sub(1, std::memory_order_release);
                 }
-                spins = 0;
                 continue;
             }
-            spins = 0;
+            // more fibers wait than spinners stand by: bring a sleeping executor in
+            if (sleepers_.load(std::memory_order_acquire) > 0 && n_ready_.load(std::memory_order_acquire) > spinners_.load(std::memory_order_acquire)) cv_.notify_one();
             if (f->finished.load(std::memory_order_acquire)) continue;                              // (a stale entry: never resume a finished fiber)
             while (f->on_cpu.exchange(true, std::memory_order_acquire)) __builtin_ia32_pause();     // still switching out elsewhere
             const int r = running_.fetch_add(1, std::memory_order_relaxed) + 1;
@@ -226,7 +237,8 @@ private:
     std::condition_variable cv_;
     std::deque<Fiber*> ready_, later_;
     std::vector<Fiber*> all_;
-    std::atomic<int> n_ready_{0}, n_front_{0}, sleepers_{0}, running_{0}, max_running_{0};
+    std::atomic<int> n_ready_{0}, n_front_{0}, sleepers_{0}, spinners_{0}, running_{0}, max_running_{0};
+    int max_spinners_ = 2;
     std::atomic<long> switches_{0};
     bool stop_ = false;
 };
