@@ -81,6 +81,8 @@ typedef struct sc_stats {
     double setup_ms;          /* the part of cluster_ms before the first level: uploads of the level-major arrays, edge support */
     double queue_ms;          /* from sc_roi_submit until a slot took the region */
     double place_ms;          /* the part of graph_ms spent waiting for one of the context's set-up places */
+    double host_us[3];        /* host work between the levels, summed over the walk: [0] the level's parameters (log tables into the
+                               * host-mapped block), [1] its results into the candidates' models + pruning, [2] candidate extension */
     long kind_levels[17];     /* levels served by each variant of the level kernel: [0] no sampler (k_level); [1 + 2 * (NB - 1) + L]
                                * the sampler for NB = ceil(candidates / 16) register blocks, L = 1 weight rows in LDS, 0 in HBM */
 } sc_stats;

@@ -24,10 +24,10 @@ class ScStats(C.Structure):
     _fields_ = [("graph_ms", C.c_double), ("cluster_ms", C.c_double), ("sampler_kernel_ms", C.c_double),
                 ("sampler_launches", C.c_long), ("sampler_read_copies", C.c_long), ("level_launches", C.c_long), ("draws", C.c_long),
                 ("slow_draws", C.c_long), ("exact_draws", C.c_long), ("sampler_strains", C.c_long), ("chain_passes", C.c_long), ("chain_cycles", C.c_long), ("chain_wall_ticks", C.c_long), ("level_kernel_ticks", C.c_long), ("sampler_level_ticks", C.c_long), ("xcd_levels", C.c_long * 8), ("msa_calls", C.c_long), ("n_nodes", C.c_int), ("n_levels", C.c_int),
-                ("n_unique_reads", C.c_int), ("n_read_copies", C.c_long), ("setup_ms", C.c_double), ("queue_ms", C.c_double), ("place_ms", C.c_double), ("kind_levels", C.c_long * 17)]
+                ("n_unique_reads", C.c_int), ("n_read_copies", C.c_long), ("setup_ms", C.c_double), ("queue_ms", C.c_double), ("place_ms", C.c_double), ("host_us", C.c_double * 3), ("kind_levels", C.c_long * 17)]
 
     def as_dict(self):
-        return {k: (list(getattr(self, k)) if k in ("xcd_levels", "kind_levels") else getattr(self, k)) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k in ("xcd_levels", "kind_levels", "host_us") else getattr(self, k)) for k, _ in self._fields_}
 
 
 class StrainCallError(RuntimeError):

@@ -186,12 +186,25 @@ typedef long double ld;               // the reference keeps abundances and coun
 // part and lives in a pool: a candidate that survives a level keeps its model where it is (no copy when the candidate
 // lists are filtered, sorted or extended), only the second and later children of a parent get a copy.
 struct Model {
-    ld sub[KK];                       // sub_count over the symbol table (stride KMAX)
+    // The tables are [ks][ks] with ks = the symbols of the region (6 for a gene of A C G T and its reads): a region in flight
+    // comes back to its models once per level, after a few hundred other regions have used the core's caches, so what a
+    // level touches is kept small and contiguous (rows of 16 entries spread the 36 live ones over four times the lines).
+    int ks = KMAX;
+    ld sub[KK];                       // sub_count over the symbol table, stride ks
     ld comp[6]; ld Z;
     ld lsub[KK];                      // logl(sub), valid where `stale` is clear
     double lpc[KK];                   // log sub(a,b) - log comp(a) as the device reads it; rows in `dirty` are stale
     uint16_t stale[KMAX];             // per row: entries whose count changed since lsub was formed
     unsigned dirty;
+    Model() = default;
+    Model(const Model& o) { *this = o; }
+    Model& operator=(const Model& o) {            // the live [ks][ks] part only
+        ks = o.ks; Z = o.Z; dirty = o.dirty;
+        const size_t n = (size_t)ks * ks;
+        std::memcpy(sub, o.sub, sizeof(ld) * n); std::memcpy(lsub, o.lsub, sizeof(ld) * n); std::memcpy(lpc, o.lpc, sizeof(double) * n);
+        std::memcpy(comp, o.comp, sizeof comp); std::memcpy(stale, o.stale, sizeof stale);
+        return *this;
+    }
 };
 struct HStrain {
     ld abundance;
@@ -777,7 +790,7 @@ static void recount(Model& s) {                                           // Str
     s.Z = 0;
     for (int i = 0; i < 6; i++) {
         s.comp[i] = 0;
-        for (int j = 0; j < 6; j++) s.comp[i] += s.sub[i * KMAX + j];
+        for (int j = 0; j < 6; j++) s.comp[i] += s.sub[i * s.ks + j];
         s.Z += s.comp[i];
     }
 }
@@ -968,8 +981,9 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         HStrain s{};
         s.model = model_new();
         Model& m = models[(size_t)s.model];
-        for (int i = 0; i < KK; i++) m.sub[i] = 0;
-        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) m.sub[i * KMAX + j] = (i == j) ? 100 * (1 - e) : 100 * e;
+        m.ks = K;
+        for (int i = 0; i < K * K; i++) m.sub[i] = 0;
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) m.sub[i * K + j] = (i == j) ? 100 * (1 - e) : 100 * e;
         recount(m);
         m.dirty = 0xFFFFu;
         for (int a = 0; a < KMAX; a++) m.stale[a] = 0xFFFFu;
@@ -983,6 +997,11 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     long sampler_launches = 0, level_launches = 0, draws = 0, exact = 0, slow = 0, sampler_copies = 0, sampler_strains = 0, passes = 0;
     unsigned long long chain_cycles = 0, chain_wall = 0, level_ticks = 0, sampler_ticks = 0;
 
+    // where the host's time between two levels goes (sc_stats.host_us): [0] parameters of the level (log tables, the
+    // host-mapped block), [1] results of the level into the candidates' models, pruning, [2] extension of the candidates
+    double host_acc[3] = {0, 0, 0};
+    double t_mark = now_ms();
+    auto lap = [&](int k) { const double t = now_ms(); host_acc[k] += t - t_mark; t_mark = t; };
     double t_last_done = now_ms();
     FILE* level_log = getenv("SC_LEVEL_LOG") ? fopen((std::string(getenv("SC_LEVEL_LOG")) + "." + std::to_string(slot)).c_str(), "a") : nullptr;   // diagnostics only
     int cur_level = 0;
@@ -1015,14 +1034,14 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 if (!(hm.dirty & (1u << a))) continue;
                 const ld lc = logl(a < 6 ? hm.comp[a] : (ld)0);                             // log comp_count[a], Strain.cpp:132-135
                 for (int b = 0; b < K; b++) {
-                    if (hm.stale[a] & (1u << b)) hm.lsub[a * KMAX + b] = logl(hm.sub[a * KMAX + b]);
-                    hm.lpc[a * KMAX + b] = (double)(hm.lsub[a * KMAX + b] - lc);
+                    if (hm.stale[a] & (1u << b)) hm.lsub[a * K + b] = logl(hm.sub[a * K + b]);
+                    hm.lpc[a * K + b] = (double)(hm.lsub[a * K + b] - lc);
                 }
                 hm.stale[a] = 0;
             }
             hm.dirty = 0;
             double* dst = P.lpt + (size_t)s * K * K;                                          // compact [K][K]
-            for (int a = 0; a < K; a++) std::memcpy(dst + a * K, hm.lpc + a * KMAX, sizeof(double) * (size_t)K);
+            std::memcpy(dst, hm.lpc, sizeof(double) * (size_t)K * K);
         }
         const bool chain = (mode == MODE_SAMPLE) && S > 1 && n_sweeps > 0;
         const bool timed = chain && pa.want_timing && !ctx->resident;      // (no launch to bracket with events when the workers are resident)
@@ -1046,6 +1065,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             ev_used += 2;
         }
         const double t_launched = level_log ? now_ms() : 0.0;
+        lap(0);
         if (ctx->resident) {
             // the slot's resident workgroup takes the level from its mailbox: the item, then its stamp (release)
             ctx->resident_ensure(this);
@@ -1095,6 +1115,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             ctx->submit_level(LevelRequest{this, LevelItem{jd_dev, H, level_kind(H) | (level_lds_kb(H, K) << 8), Pm, Rd}, level_kind(H), timed});
             wait_level();
         }
+        t_mark = now_ms();                                   // (the wait for the level is not host work)
         level_launches++;
         if (chain) {
             sampler_launches++; sampler_copies += Q;
@@ -1183,7 +1204,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 for (int s = 0; s < S; s++) prior[s] = level_strains[last[s]].abundance;
                 run_level(MODE_SAMPLE, e0, e1, Q, n, true, level_strains, has_dups, any_multi);
                 ld (*cnt)[KMAX] = reinterpret_cast<ld (*)[KMAX]>(cnt_scratch.data());     // (not thread_local: the fiber changes threads)
-                for (int s = 0; s < S; s++) for (int b = 0; b < KMAX; b++) cnt[s][b] = 0;
+                for (int s = 0; s < S; s++) for (int b = 0; b < K; b++) cnt[s][b] = 0;
                 if (S == 1 || n <= 0) {
                     // a single weight consumes no random numbers (libstdc++ discrete_distribution)
                     a[0] = level_strains[0].abundance;
@@ -1197,7 +1218,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 } else {
                     for (int s = 0; s < S; s++) {
                         a[s] = sc_add_ones(level_strains[s].abundance, Rh->kdraw[s]);     // a[c] += 1 per draw, :195 (one rounding per draw)
-                        for (int b = 0; b < KMAX; b++) cnt[s][b] = (ld)Rh->cnt[s * KMAX + b];
+                        for (int b = 0; b < K; b++) cnt[s][b] = (ld)Rh->cnt[s * KMAX + b];
                     }
                 }
                 ld z = 0;
@@ -1210,9 +1231,9 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                     st_.abundance += a[s];                                   // update_model, Strain.cpp:106-125
                     if (f.node_lab_len[st_.node] == 1) {
                         const int la = f.labels[f.node_lab_off[st_.node]];
-                        if (la < KMAX) {
+                        if (la < K) {
                             for (int b = 0; b < K; b++)
-                                if (cnt[s][b] > 0) { m_.sub[la * KMAX + b] += cnt[s][b] / n; m_.stale[la] |= (uint16_t)(1u << b); }
+                                if (cnt[s][b] > 0) { m_.sub[la * K + b] += cnt[s][b] / n; m_.stale[la] |= (uint16_t)(1u << b); }
                             m_.dirty |= 1u << la;
                         }
                     }
@@ -1242,7 +1263,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                     for (int a = 0; a < K; a++)
                         for (int b = 0; b < K; b++) {
                             const double d = sub_d[a * K + b];
-                            m_.sub[a * KMAX + b] += (ld)d;
+                            m_.sub[a * K + b] += (ld)d;
                             if (d != 0.0) { m_.dirty |= 1u << a; m_.stale[a] |= (uint16_t)(1u << b); }
                         }
                     recount(m_);
@@ -1250,6 +1271,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             }
         }
         trace_dump("after clustering", level, level_strains);
+        lap(1);
 
         // ---- candidate extension, :473-551
         branching = false;
@@ -1312,6 +1334,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         }
         level_strains.swap(sub_strains);
         sub_strains.clear();
+        lap(2);
     }
 
     // ---- read_assign, :776-836, then the final sort, StrainCall.cpp:1027
@@ -1355,6 +1378,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         sampler_ms += ms;
     }
     ev_used = 0;
+    for (int k = 0; k < 3; k++) job.stats.host_us[k] = 1e3 * host_acc[k];
     job.stats.sampler_kernel_ms = sampler_ms;
     job.stats.sampler_launches = sampler_launches;
     job.stats.sampler_read_copies = sampler_copies;
@@ -1486,8 +1510,11 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
     {
         // resident level workers: one workgroup per slot holds a CU (and all of its LDS) while regions are in flight, so the
         // slots stop short of the 256 CUs -- the set-up kernels of the regions (read threading, MSA, edge support) need CUs too
+        // Default: resident workers when several regions are in flight (no launch per level, no stream held by the slowest
+        // level of a batch: +30-60 % reads/s at 128-224 in flight); a launch per level for a single region (its level
+        // kernels are then kernels of their own, which the compiler allocates ~5 % faster than the same code behind a call).
         const char* e = getenv("SC_RESIDENT");
-        ctx->resident = e ? atoi(e) != 0 : false;
+        ctx->resident = e ? atoi(e) != 0 : stream_count > 1;
         const char* rs = getenv("SC_RESIDENT_SLOTS");
         // Measured on MI355X: 224 resident workgroups (8 wavefronts each, 1 792 in all) start, the ones beyond do not (232: their
         // regions wait for ever, or the grid faults) -- the kernel keeps its variants as functions, their stack frames live in

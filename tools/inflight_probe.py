@@ -69,6 +69,10 @@ def main():
                 time.sleep(0.0005)
         import resource
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
+        try:
+            cs0 = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        except OSError:
+            cs0 = {}
         t0 = time.time()
         _, stats = stage5.run_regions(ctx, prep, r, params)
         t_end = time.time()
@@ -90,6 +94,13 @@ def main():
         rec["setup_ms"] = round(sum(s["setup_ms"] for s in stats) / n, 1)
         rec["queue_ms"] = round(sum(s["queue_ms"] for s in stats) / n, 1)
         rec["place_ms"] = round(sum(s["place_ms"] for s in stats) / n, 1)
+        rec["host_us_per_level"] = [round(sum(s["host_us"][k] for s in stats) / max(sum(s["level_launches"] for s in stats), 1), 1) for k in range(3)]
+        try:
+            cs1 = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+            rec["throttled_ms"] = round((int(cs1["throttled_usec"]) - int(cs0["throttled_usec"])) / 1e3, 1)
+            rec["nr_throttled"] = int(cs1["nr_throttled"]) - int(cs0["nr_throttled"])
+        except (OSError, KeyError, ValueError, NameError):
+            pass
         rec["knobs"] = {k: os.environ[k] for k in ("SC_EXEC_THREADS", "SC_SETUP_LIMIT", "SC_RESIDENT_SLOTS") if k in os.environ}
         rec["gap_us_per_level"] = round(1e3 * (rec["cluster_ms"] - rec["setup_ms"] - rec["level_kernel_ms"]) / max(rec["levels"], 1), 1)
         # share of the GPU's 256 CUs that held a level workgroup, averaged over the run
