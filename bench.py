@@ -445,7 +445,10 @@ def main():
     regions = cli.load_regions(pa)                       # host ingest (rows a1-a4), outside the headline's timed region
     n_graph = sum(sum(r.copies) for _, r in regions)
     params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate), want_timing=True)
-    ctx = make_context(local, 1, resident)
+    # a single region: one launch per level (its level kernels are kernels of their own: ~5 % fewer chain cycles than the same
+    # code behind a call in the resident workgroup, and HIP events bracket every launch); resident workers are for many regions
+    ctx = make_context(local, 1, False)
+    single_mode = "one launch per level, straight from the region's host thread (a single region in flight)"
 
     def step(prepared, c=None):
         texts, stats = stage5.run_regions(c or ctx, prepared, 1, params)
@@ -470,24 +473,7 @@ def main():
     fence()
     dt_ingest = time.time() - t0
     ctx.close()
-    # the dominant kernel timed with HIP events needs a launch per level: a few steps through the level server
-    launch_stats, launch_ms_per_step = all_stats, None
-    if resident:
-        ctx_l = make_context(local, 1, False)
-        step([(pa, regions)], ctx_l)
-        fence()
-        t1 = time.time()
-        launch_stats = []
-        n_l = min(a.steps, 3)
-        for _ in range(n_l):
-            fa_l, st = step([(pa, regions)], ctx_l)
-            launch_stats += st
-        fence()
-        launch_ms_per_step = 1e3 * (time.time() - t1) / n_l
-        ctx_l.close()
-        assert fa_l == fasta_out, "launch-per-level and resident level workers disagree"
-    rl = roofline(launch_stats, len(launch_stats), 1)
-    rl["resident_level_ms"] = sum(s["sampler_level_ticks"] for s in all_stats) / 1e5 / max(sum(s["sampler_launches"] for s in all_stats), 1)
+    rl = roofline(all_stats, a.steps, 1)
 
     line = {"metric": "reads/sec into POA (150bp, ~1.5k-node graph)", "value": a.reads * a.steps / dt, "unit": "reads/s",
             "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -496,18 +482,16 @@ def main():
             "config": {"workload": "configs[1]: %d x 150bp reads vs one %dbp gene, %d strains, seed 21, rambl.py options (%s)" % (
                 a.reads, a.glen, a.strains, RAMBL_OPTS),
                 "regions_per_gpu": 1, "regions_in_flight_per_gpu": 1, "parallelism": "one region, one GPU (a single region does not shard: replicas only)",
-                "level_execution": mode, "input_reads": a.reads, "read_copies_after_ingest": n_graph},
+                "level_execution": single_mode, "input_reads": a.reads, "read_copies_after_ingest": n_graph},
             "roofline": rl,
             "breakdown_ms_per_step": breakdown(all_stats, a.steps),
             "contigs": fasta_out.count(">") if fasta_out else 0,
             "with_ingest_matches": with_ingest == fasta_out}
-    if launch_ms_per_step is not None:
-        line["ms_per_step_launch_per_level"] = launch_ms_per_step
     if not a.no_cpu:
         cb, cargs = cpu_baseline(d, fasta, sam, "gene21:%s" % a.sample_roi)
         ref_fa = cb.pop("fasta")
         # the same sample on the GPU (ingest inside the clock, as the CPU figure has it): the like-for-like ratio
-        ctx2 = make_context(local, 1, resident)
+        ctx2 = make_context(local, 1, False)
         pa2 = cli.parse_cmd_line(cargs)
         stage5.run_regions(ctx2, [(pa2, cli.load_regions(pa2))], 1)
         t1 = time.time()

@@ -251,6 +251,7 @@ struct Ctx {
     // executor threads only, so that the others stay free for the continuations of the regions in flight.
     std::atomic<int> setups{0};
     int setup_limit = 1;
+    bool split_exec = false;                  // the pool has threads of its own for the set-ups
     void setup_enter();
     void setup_leave() { setups.fetch_sub(1, std::memory_order_release); }
     LevelParams* P_all = nullptr;             // host-mapped blocks of all slots (one allocation each)
@@ -786,6 +787,20 @@ void Worker::thread_device(const std::string& G, const std::vector<AlignedRead>&
     fix(T.minrid); fix(T.smin); fix(T.emin); fix(T.tmin);
 }
 
+// ... and the same for the rows of `rows` only: a row whose counts did not change keeps its sum (the same additions in the
+// same order give the same long double), and a level changes one row of a candidate -- its model is cold in the caches
+// by the time the region comes back to it, so the lines it touches count
+static void recount_rows(Model& s, unsigned rows) {
+    rows &= 0x3Fu;
+    if (!rows) return;
+    for (int i = 0; i < 6; i++) {
+        if (!(rows & (1u << i))) continue;
+        s.comp[i] = 0;
+        for (int j = 0; j < 6; j++) s.comp[i] += s.sub[i * s.ks + j];
+    }
+    s.Z = 0;
+    for (int i = 0; i < 6; i++) s.Z += s.comp[i];
+}
 static void recount(Model& s) {                                           // Strain.cpp:115-124
     s.Z = 0;
     for (int i = 0; i < 6; i++) {
@@ -1229,15 +1244,17 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                     HStrain& st_ = level_strains[s];
                     Model& m_ = models[(size_t)st_.model];
                     st_.abundance += a[s];                                   // update_model, Strain.cpp:106-125
+                    unsigned changed = 0;
                     if (f.node_lab_len[st_.node] == 1) {
                         const int la = f.labels[f.node_lab_off[st_.node]];
                         if (la < K) {
                             for (int b = 0; b < K; b++)
                                 if (cnt[s][b] > 0) { m_.sub[la * K + b] += cnt[s][b] / n; m_.stale[la] |= (uint16_t)(1u << b); }
                             m_.dirty |= 1u << la;
+                            changed = 1u << la;
                         }
                     }
-                    recount(m_);
+                    recount_rows(m_, changed);
                 }
                 for (int s = 0; s < S; s++) post[s] = level_strains[last[s]].abundance;
                 ld A_delta_max = 0;
@@ -1260,13 +1277,16 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                     Model& m_ = models[(size_t)st_.model];
                     st_.abundance += (ld)Rh->abund[s];
                     const double* sub_d = Rh->subst + (size_t)s * K * K;      // compact [K][K]
+                    unsigned changed = 0;
                     for (int a = 0; a < K; a++)
                         for (int b = 0; b < K; b++) {
                             const double d = sub_d[a * K + b];
-                            m_.sub[a * K + b] += (ld)d;
-                            if (d != 0.0) { m_.dirty |= 1u << a; m_.stale[a] |= (uint16_t)(1u << b); }
+                            if (d != 0.0) {                                   // (x + 0.0 == x for every x the counts can hold: they are never -0)
+                                m_.sub[a * K + b] += (ld)d;
+                                m_.dirty |= 1u << a; m_.stale[a] |= (uint16_t)(1u << b); changed |= 1u << a;
+                            }
                         }
-                    recount(m_);
+                    recount_rows(m_, changed);
                 }
             }
         }
@@ -1406,6 +1426,7 @@ void Worker::process(Job& job) {
         ~Setup() { if (w->setup_held) { w->ctx->setup_leave(); w->setup_held = false; } }
     } setup{this};
     job.stats.queue_ms = t0 - job.t_submit;
+    if (ctx->split_exec) FiberPool::yield();           // the set-up belongs on one of the pool's set-up threads
     ctx->setup_enter();
     setup_held = true;
     job.stats.place_ms = now_ms() - t0;
@@ -1600,7 +1621,13 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         });
     }
     const int dev = device;
-    ctx->pool.reset(new FiberPool(plan[0], [dev] { (void)hipSetDevice(dev); }));
+    // half of the executor threads take the regions' set-ups first (graph construction: tens of milliseconds each), the other
+    // half never do: the continuation of a region whose level has come back is a few tens of microseconds and must not wait
+    int n_long = plan[0] >= 2 ? plan[0] / 2 : 0;
+    if (const char* e = getenv("SC_EXEC_LONG")) n_long = std::max(0, std::min(atoi(e), plan[0] - 1));
+    ctx->split_exec = n_long > 0;
+    if (!getenv("SC_SETUP_LIMIT") && n_long > 0) ctx->setup_limit = 2 * n_long;      // a set-up waits for the GPU part of its time
+    ctx->pool.reset(new FiberPool(plan[0], [dev] { (void)hipSetDevice(dev); }, n_long));
     if (stream_count > 1) ctx->server = std::thread([ctx] { ctx->serve_levels(); });
     ctx->fibers_left.store(stream_count, std::memory_order_release);
     for (auto& w : ctx->workers) {

@@ -74,12 +74,17 @@ struct Fiber {
 
 class FiberPool {
 public:
-    // n_threads executor threads; `on_thread_start` runs once on each (hipSetDevice)
-    explicit FiberPool(int n_threads, std::function<void()> on_thread_start = nullptr)
+    // n_threads executor threads, of which n_long take the fibers that were made ready with `later` first (the long,
+    // CPU-bound stretches: a region's set-up) and the others never do: a continuation of a region whose level has come back
+    // (a few tens of microseconds) does not wait behind a graph construction (tens of milliseconds).  With n_long = 0 every
+    // thread takes both.  `on_thread_start` runs once on each (hipSetDevice).
+    explicit FiberPool(int n_threads, std::function<void()> on_thread_start = nullptr, int n_long = 0)
         : on_start_(std::move(on_thread_start)) {
         if (n_threads < 1) n_threads = 1;
+        if (n_long < 0 || n_long >= n_threads) n_long = 0;
+        split_ = n_long > 0;
         if (const char* e = getenv("SC_EXEC_SPINNERS")) max_spinners_ = atoi(e) < 0 ? 0 : atoi(e);
-        for (int i = 0; i < n_threads; i++) threads_.emplace_back([this] { run(); });
+        for (int i = 0; i < n_threads; i++) { const bool lng = i >= n_threads - n_long; threads_.emplace_back([this, lng] { run(lng); }); }
     }
     ~FiberPool() { shutdown(); }
     FiberPool(const FiberPool&) = delete;
@@ -126,6 +131,7 @@ public:
         }
         if (!later) n_front_.fetch_add(1, std::memory_order_release);
         const int nr = n_ready_.fetch_add(1, std::memory_order_release) + 1;
+        if (later && split_) { if (long_sleepers_.load(std::memory_order_acquire) > 0) cv_long_.notify_one(); return; }
         // a spinning executor sees the counter at once; a sleeping one is woken only when no spinner is there to take this
         // fiber (a futex call per level would cost the level server more than the level's own bookkeeping)
         if (sleepers_.load(std::memory_order_acquire) > 0 && nr > spinners_.load(std::memory_order_acquire)) cv_.notify_one();
@@ -157,6 +163,7 @@ public:
             stop_ = true;
         }
         cv_.notify_all();
+        cv_long_.notify_all();
         for (auto& t : threads_) if (t.joinable()) t.join();
         for (Fiber* f : all_) { if (f->stack) munmap(f->stack, f->stack_bytes); delete f; }
         all_.clear();
@@ -183,7 +190,7 @@ private:
         sc_fiber_switch(&f->sp, *f->back);
         __builtin_trap();
     }
-    void run() {
+    void run(bool lng) {
         if (on_start_) on_start_();
         void* self_sp = nullptr;
         unsigned spins = 0;
@@ -191,31 +198,35 @@ private:
             Fiber* f = nullptr;
             if (n_ready_.load(std::memory_order_acquire) > 0) {
                 std::lock_guard<std::mutex> lk(mu_);
-                if (!ready_.empty()) { f = ready_.front(); ready_.pop_front(); n_ready_.fetch_sub(1, std::memory_order_relaxed); n_front_.fetch_sub(1, std::memory_order_relaxed); }
-                else if (!later_.empty()) { f = later_.front(); later_.pop_front(); n_ready_.fetch_sub(1, std::memory_order_relaxed); }
+                auto take_front = [&] { f = ready_.front(); ready_.pop_front(); n_ready_.fetch_sub(1, std::memory_order_relaxed); n_front_.fetch_sub(1, std::memory_order_relaxed); };
+                auto take_later = [&] { f = later_.front(); later_.pop_front(); n_ready_.fetch_sub(1, std::memory_order_relaxed); };
+                if (lng) { if (!later_.empty()) take_later(); else if (!ready_.empty()) take_front(); }
+                else { if (!ready_.empty()) take_front(); else if (!split_ && !later_.empty()) take_later(); }
             }
             if (!f) {
-                // Nothing ready.  A rank's CPU share is a quota of CPU TIME (a GPU box hands out 16 CPUs of its host as a cgroup
-                // bandwidth limit): an executor that spins spends the quota the regions' bookkeeping needs.  So at most
-                // `max_spinners_` executors wait by spinning (they pick a level's continuation up within a fraction of a
-                // microsecond); the others sleep and are woken when fibers queue up behind the spinners.
-                if (spinners_.load(std::memory_order_acquire) < max_spinners_) {
+                // Nothing ready (for this kind of thread).  A rank's CPU share is a quota of CPU TIME (a GPU box hands out 16
+                // CPUs of its host as a cgroup bandwidth limit): an executor that spins spends the quota the regions'
+                // bookkeeping needs.  So at most `max_spinners_` executors wait by spinning (they pick a level's continuation
+                // up within a fraction of a microsecond); the others sleep and are woken when fibers queue up behind the spinners.
+                if (!lng && spinners_.load(std::memory_order_acquire) < max_spinners_) {
                     spinners_.fetch_add(1, std::memory_order_acq_rel);
-                    for (spins = 0; spins < 6000 && n_ready_.load(std::memory_order_acquire) == 0; spins++) __builtin_ia32_pause();
+                    for (spins = 0; spins < 6000 && n_front_.load(std::memory_order_acquire) == 0 && (split_ || n_ready_.load(std::memory_order_acquire) == 0); spins++) __builtin_ia32_pause();
                     spinners_.fetch_sub(1, std::memory_order_acq_rel);
                     if (n_ready_.load(std::memory_order_acquire) > 0) continue;
                 }
                 std::unique_lock<std::mutex> lk(mu_);
-                if (stop_ && ready_.empty() && later_.empty()) return;
-                if (ready_.empty() && later_.empty()) {
-                    sleepers_.fetch_add(1, std::memory_order_release);
-                    cv_.wait_for(lk, std::chrono::milliseconds(20), [&] { return stop_ || !ready_.empty() || !later_.empty(); });
-                    sleepers_.fetch_sub(1, std::memory_order_release);
+                auto mine = [&] { return lng ? (!later_.empty() || !ready_.empty()) : (!ready_.empty() || (!split_ && !later_.empty())); };
+                if (stop_ && !mine()) return;
+                if (!mine()) {
+                    std::atomic<int>& sl = lng ? long_sleepers_ : sleepers_;
+                    sl.fetch_add(1, std::memory_order_release);
+                    (lng ? cv_long_ : cv_).wait_for(lk, std::chrono::milliseconds(lng ? 5 : 20), [&] { return stop_ || mine(); });
+                    sl.fetch_sub(1, std::memory_order_release);
                 }
                 continue;
             }
             // more fibers wait than spinners stand by: bring a sleeping executor in
-            if (sleepers_.load(std::memory_order_acquire) > 0 && n_ready_.load(std::memory_order_acquire) > spinners_.load(std::memory_order_acquire)) cv_.notify_one();
+            if (sleepers_.load(std::memory_order_acquire) > 0 && n_front_.load(std::memory_order_acquire) > spinners_.load(std::memory_order_acquire)) cv_.notify_one();
             if (f->finished.load(std::memory_order_acquire)) continue;                              // (a stale entry: never resume a finished fiber)
             while (f->on_cpu.exchange(true, std::memory_order_acquire)) __builtin_ia32_pause();     // still switching out elsewhere
             const int r = running_.fetch_add(1, std::memory_order_relaxed) + 1;
@@ -234,11 +245,12 @@ private:
     std::function<void()> on_start_;
     std::vector<std::thread> threads_;
     std::mutex mu_;
-    std::condition_variable cv_;
+    std::condition_variable cv_, cv_long_;
     std::deque<Fiber*> ready_, later_;
     std::vector<Fiber*> all_;
-    std::atomic<int> n_ready_{0}, n_front_{0}, sleepers_{0}, spinners_{0}, running_{0}, max_running_{0};
-    int max_spinners_ = 2;
+    std::atomic<int> n_ready_{0}, n_front_{0}, sleepers_{0}, long_sleepers_{0}, spinners_{0}, running_{0}, max_running_{0};
+    int max_spinners_ = 4;
+    bool split_ = false;
     std::atomic<long> switches_{0};
     bool stop_ = false;
 };

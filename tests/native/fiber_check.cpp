@@ -34,6 +34,7 @@ struct Region {
 
 int main(int argc, char** argv) {
     const int R = argc > 1 ? atoi(argv[1]) : 512, T = argc > 2 ? atoi(argv[2]) : 4, L = argc > 3 ? atoi(argv[3]) : 300;
+    const int TL = argc > 4 ? atoi(argv[4]) : 0;            // of the T threads: those that take the `later` fibers first
     std::vector<Region> regs((size_t)R);
     std::mutex mu;
     std::vector<Region*> posted;
@@ -41,7 +42,7 @@ int main(int argc, char** argv) {
     std::atomic<bool> stop{false};
     int max_threads = 0;
     {
-        FiberPool pool(T);
+        FiberPool pool(T, nullptr, TL);
         // the level server: takes what was posted, "runs" it, makes the fiber ready again
         std::thread server([&] {
             std::vector<Region*> mine;

@@ -526,34 +526,65 @@ def test_msa_kernel_on_the_reference_vectors():
 
 def test_every_wide_sampler_variant_is_exercised(tmp_path):
     """The sampler kernel has one variant per 16 candidates (NB = 1..8) and per home of the weight rows (LDS / HBM).  Under
-    the reference's cap of 80 candidates (NonparametricClustering.cpp:532-551) the 50-strain region of config4_deep reaches
-    NB = 6; with the cap raised to 120 (sc_params.max_candidates; SC_ORACLE_MAX_CANDIDATES for the oracle, whose stdout is
-    tests/golden/config4_deep_cap120) levels with up to 128 candidates run NB = 7 and 8 too.  The histogram of sc_stats
-    says which variants served the levels: none of NB = 5..8 may go unexercised, and the FASTA must equal the fixtures."""
+    the reference's cap of 80 candidates (NonparametricClustering.cpp:532-551) no committed data set goes beyond NB = 5
+    (config4_deep: 72 candidates at most); tests/golden/wide_cap120 is a region of 100 strains walked with the cap raised
+    to 120 (sc_params.max_candidates; SC_ORACLE_MAX_CANDIDATES for the oracle, whose output the fixture holds): up to 122
+    candidates at a level.  The FASTA must equal the fixture; at every trace block the candidates (number, sequences in
+    order) must be the oracle's and their abundances must add up to the oracle's sum to 1e-9; and the histogram of
+    sc_stats must show every variant NB = 1..8 at work -- so the wide variants cannot lose their coverage unnoticed."""
+    import gzip
     import hashlib
     import json
     from rambl_amd import capi, cli, synth
-    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    meta = json.load(open(os.path.join(gold, "config4_deep", "meta.json")))
-    gene = synth.make_gene(4, glen=1500, n_strains=50, n_reads=100000, name="deep4")
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wide_cap120")
+    meta = json.load(open(os.path.join(gold, "meta.json")))
+    gene = synth.make_gene(77, glen=600, n_strains=100, n_reads=30000, name="wide", n_sub=12, err=0.01)
     fa, sam = synth.write_dataset(str(tmp_path), [gene])
     assert hashlib.sha256(open(sam, "rb").read()).hexdigest() == meta["sam_sha256"]
+    assert hashlib.sha256(open(fa, "rb").read()).hexdigest() == meta["fasta_sha256"]
     pa = cli.parse_cmd_line(meta["argv"] + [fa, sam])
     regions = cli.load_regions(pa)
+    params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate), want_trace=True)
+    params.max_candidates = meta["max_candidates"]
     hist = [0] * 17
-    with capi.Context(0, 2) as ctx:
-        hs = []
-        for cap in (80, 120):
-            params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate))
-            params.max_candidates = cap
-            hs.append([(w, ctx.submit(r, params)) for w, r in regions])
-        for cap, handles, name in ((80, hs[0], "config4_deep"), (120, hs[1], "config4_deep_cap120")):
-            text = ""
-            for w, h in handles:
-                res = ctx.wait(h)
-                text += cli.format_fasta(w, res, pa.tau)
-                hist = [a + b for a, b in zip(hist, res.stats["kind_levels"])]
-            assert text == open(os.path.join(gold, name, "expected.fa")).read(), name
+    text, blocks = "", []
+    with capi.Context(0, 1) as ctx:
+        for w, r in regions:
+            res = ctx.wait(ctx.submit(r, params), want_trace=True)
+            text += cli.format_fasta(w, res, pa.tau)
+            hist = [x + y for x, y in zip(hist, res.stats["kind_levels"])]
+            for when, level, rows in T.parse_trace(res.trace):
+                h = hashlib.sha1()
+                for seq, _ in rows:
+                    h.update(seq.encode())
+                    h.update(b"\n")
+                blocks.append([when, level, len(rows), sum(ab for _, ab in rows), h.hexdigest()[:16]])
+    assert text == open(os.path.join(gold, "expected.fa")).read()
+    exp = json.loads(gzip.open(os.path.join(gold, "expected_levels.json.gz")).read())
+    assert len(blocks) == len(exp) == meta["trace_blocks"]
+    for g, e in zip(blocks, exp):
+        assert g[:3] == e[:3] and g[4] == e[4], (g, e)
+        tot = float(e[3])
+        assert abs(g[3] - tot) <= 1e-9 * max(abs(tot), 1e-300), (g, e)
+    assert max(b[2] for b in blocks) == meta["max_candidates_at_a_level"] > 112
     by_nb = {nb: hist[1 + 2 * (nb - 1)] + hist[2 + 2 * (nb - 1)] for nb in range(1, 9)}
-    assert all(by_nb[nb] > 0 for nb in (5, 6, 7, 8)), by_nb
-    assert sum(hist) > 2000
+    assert all(by_nb[nb] > 0 for nb in range(1, 9)), by_nb
+
+
+def test_launch_per_level_path_with_many_regions_in_flight():
+    """Several regions in flight run on resident level workers by default; the other way of running their levels -- one launch
+    per level through the level server, levels of different kinds leaving as one grid (k_level_any) -- stays in the library
+    (SC_RESIDENT=0; a single region always uses a launch per level) and must keep giving the reference's results.  The
+    tests that put regions of very different shapes in flight together are run again that way, in a child process with its
+    own time limit (a hang of either path ends there, not in this process)."""
+    import subprocess
+    import sys
+    if os.environ.get("SC_TEST_CHILD"):
+        pytest.skip("already the child")
+    env = dict(os.environ, SC_RESIDENT="0", SC_TEST_CHILD="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                        "mixed_kinds or regions_in_flight_are_independent or stage5_many_regions"], env=env, timeout=900,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    tail = p.stdout.decode()[-1500:]
+    assert p.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail

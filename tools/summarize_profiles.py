@@ -32,7 +32,7 @@ def counter_avgs(path, counter):
                 continue
             name = row["Kernel_Name"]
             key = None
-            for fam in ("k_level_sample", "k_depth_segments", "k_depth_mark", "k_level_copy", "k_level_update"):
+            for fam in ("k_level_sample", "k_level_resident", "k_level_any", "k_depth_fused", "k_level_copy", "k_level_update"):
                 if fam in name:
                     key = fam
                     break
@@ -50,6 +50,15 @@ def main():
     tag = sys.argv[5] if len(sys.argv) > 5 else "bench_config2"
     os.makedirs(out, exist_ok=True)
     shutil.copy(find(stats_dir, "_kernel_stats.csv"), os.path.join(out, tag + "_kernel_stats.csv"))
+    # the spread of the level kernels' durations (a stall of the queues -- round 2's pageable copies -- shows as a maximum
+    # tens of times the average)
+    spread = {}
+    with open(find(stats_dir, "_kernel_stats.csv"), newline="") as f:
+        for row in csv.DictReader(f):
+            if "k_level" in row["Name"]:
+                spread[row["Name"]] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "max_us": float(row["MaxNs"]) / 1e3,
+                                       "stddev_us": float(row["StdDev"]) / 1e3}
+    json.dump(spread, open(os.path.join(out, tag + "_level_kernel_spread.json"), "w"), indent=1)
     with open(find(stats_dir, "_kernel_trace.csv"), "rb") as f, gzip.open(os.path.join(out, tag + "_kernel_trace.csv.gz"), "wb") as g:
         shutil.copyfileobj(f, g)
     fpath, wpath = find(fetch_dir, "_counter_collection.csv"), find(write_dir, "_counter_collection.csv")
