@@ -1031,6 +1031,14 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         H.copy_n = do_update ? level_hi[(size_t)cur_level] : n_reads;
         for (int c = 0; c < H.n_copy; c++) { P.copy_src[c] = pending_copies[c].first; P.copy_dst[c] = pending_copies[c].second; }
         pending_copies.clear();
+        {   // every candidate owns its row of the read log-likelihood matrix
+            uint64_t seen[2] = {0, 0};
+            for (int s = 0; s < S; s++) {
+                const int r = sv[s].slot;
+                if (r < 0 || r >= MAXS || (seen[r >> 6] >> (r & 63)) & 1) throw ScError(SC_ERR_INTERNAL, "two candidates share a read_loglik row");
+                seen[r >> 6] |= 1ull << (r & 63);
+            }
+        }
         ld za = 0;
         for (int s = 0; s < S; s++) za += sv[s].abundance;                 // normalize(), :10-15
         for (int s = 0; s < S; s++) {

@@ -1473,7 +1473,13 @@ bool level_wants_grid(const JobDev& job, const LevelHdr& h) {
 int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* Pd) {
     const int S = h.S, Rn = h.e1 - h.e0;
     int done = 0;
-    if ((long)h.n_copy * job.n_reads > GRID_COPY_WORDS) {
+    const bool update_on_grid = h.do_update && (long)S * Rn > GRID_ITEMS && !h.has_dups && !h.any_multi;
+    // The rows of the level's new candidates come first, whoever makes them: a candidate's row must be its parent's row of
+    // BEFORE this level's update.  (Until round 3 the update could go to the grid while a few small copies stayed with the
+    // level's own kernel, which then copied the parent's already updated row over the child's: the child was scored with its
+    // parent's symbol at this level.  Levels of more than 131 072 (candidate, read) items with fewer than 2^19 / reads new
+    // candidates -- tests/golden/wide_cap120 found it at 121 candidates x 1 085 reads.)
+    if (h.n_copy > 0 && ((long)h.n_copy * job.n_reads > GRID_COPY_WORDS || update_on_grid)) {
         const int n2 = (job.n_reads + 1) >> 1;
         int bx = (n2 + 1023) / 1024;
         bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
@@ -1481,7 +1487,7 @@ int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, cons
         done |= LV_COPIES_DONE;
     }
     const long items = (long)S * Rn;
-    if (h.do_update && items > GRID_ITEMS && !h.has_dups && !h.any_multi) {
+    if (update_on_grid) {
         int g = (int)((items + 511) / 512);
         g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
         hipLaunchKernelGGL(k_level_update, dim3(g), dim3(256), 0, st, job, h, Pd);

@@ -482,6 +482,27 @@ def test_config4_million_reads_match_reference(depth, million_reads):
     assert got == open(os.path.join(gold, "expected.fa")).read()
 
 
+def test_grid_levels_on_resident_workers(million_reads):
+    """Levels with more than 131 072 (candidate, read) items send their row copies and log-likelihood update to a grid of
+    their own (k_level_copy, k_level_update) before the level's workgroup takes over.  With several regions in flight that
+    workgroup is a RESIDENT one: it has to see what kernels on other CUs (other XCDs) have just written to rows it read at
+    the level before.  The -D 3000 region (3 000 read copies per level: grid updates from ~45 candidates on) twice in a
+    two-slot context, both against the reference's FASTA."""
+    import json
+    from rambl_amd import capi, cli
+    fa, sam = million_reads
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config4_full_D3000")
+    meta = json.load(open(os.path.join(gold, "meta.json")))
+    pa = cli.parse_cmd_line(meta["argv"] + [fa, sam])
+    regions = cli.load_regions(pa)
+    params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate))
+    exp = open(os.path.join(gold, "expected.fa")).read()
+    with capi.Context(0, 2) as ctx:
+        hs = [[(w, ctx.submit(r, params)) for w, r in regions] for _ in range(2)]
+        for handles in hs:
+            assert "".join(cli.format_fasta(w, ctx.wait(h), pa.tau) for w, h in handles) == exp
+
+
 def test_config4_million_reads_unthinned_matches_oracle(million_reads):
     """configs[3] with no thinning at all (-D 100000): every one of the 10^6 reads reaches the graph (~590 000 distinct
     reads, ~100 000 read copies per level: the closed-form levels, grid updates, 600 MB of pools).  The reference cannot

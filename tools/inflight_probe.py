@@ -80,7 +80,7 @@ def main():
         ctx.close()
         n = len(stats)
         rec = dict(regions=len(prep), in_flight=r, seconds=round(dt, 3), reads_per_s=round(len(prep) * reads / dt),
-                   resident=os.environ.get("SC_RESIDENT", "0"),
+                   level_execution=("launch per level" if os.environ.get("SC_RESIDENT", "1" if r > 1 else "0") == "0" else "resident workers"),
                    cluster_ms=round(sum(s["cluster_ms"] for s in stats) / n, 1),
                    graph_ms=round(sum(s["graph_ms"] for s in stats) / n, 1),
                    level_kernel_ms=round(sum(s["level_kernel_ticks"] for s in stats) / n / 1e5, 1),
