@@ -286,8 +286,8 @@ def main():
     ap.add_argument("--no-depth", action="store_true", help="N = 1: skip the stage-1 depth-scan leg (hbm_bound_kernel)")
     ap.add_argument("--no-saturation", action="store_true", help="skip the saturation leg (regions of the configs[1] shape in flight)")
     ap.add_argument("--launch-mode", action="store_true", help="one launch per level (the level server) instead of resident level workers")
-    ap.add_argument("--streams", type=int, default=232, help="regions in flight per GPU (slots of the context)")
-    ap.add_argument("--sat-points", default="64,128,232", help="N = 1: regions in flight of the saturation curve")
+    ap.add_argument("--streams", type=int, default=224, help="regions in flight per GPU (slots of the context; resident workers: at most 224)")
+    ap.add_argument("--sat-points", default="64,128,224", help="N = 1: regions in flight of the saturation curve")
     ap.add_argument("--sat-rounds", type=int, default=3)
     ap.add_argument("--sat-distinct", type=int, default=32, help="distinct data sets of the saturation leg (reused cyclically)")
     a = ap.parse_args()
