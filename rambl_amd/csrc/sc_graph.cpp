@@ -2,6 +2,8 @@
 // reference lines whose behaviour it reproduces
 // (/root/reference/StrainCall/PartialOrderGraph.cpp unless another file is named).
 #include "sc_graph.hpp"
+#include <chrono>
+#include <cstdio>
 
 #include <algorithm>
 #include <cstring>
@@ -793,12 +795,21 @@ PoGraph::PoGraph(const std::string& G, const std::vector<AlignedRead>& R, const 
     }
     int E = new_node(ST_MAT, "$");
     add_edge(u, E);
+#ifdef SC_GRAPH_TIMING
+    auto now_ = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tp_ = now_();
+#define SC_PHASE(name) do { const double t_ = now_(); fprintf(stderr, "  graph phase %-18s %.2f ms\n", name, t_ - tp_); tp_ = t_; } while (0)
+#else
+#define SC_PHASE(name) do {} while (0)
+#endif
     thread_reads(G, R, thread);
+    SC_PHASE("thread_reads");
     // canonize_graph, cpp:754-767
     for (int i = 0; i < (int)nodes.size(); ++i) {            // canonize_insert :553-564
         if (nodes[i].lab == "$") break;
         canonize_insert_at_level(i);
     }
+    SC_PHASE("canonize_insert");
     level_cache_build();
     level_cache_on_ = true;
     for (int i = 0; i < (int)nodes.size(); ++i) {            // canonize_delete :742-752
@@ -807,11 +818,17 @@ PoGraph::PoGraph(const std::string& G, const std::vector<AlignedRead>& R, const 
     }
     level_cache_on_ = false;
     std::vector<int>().swap(level_cache_);
+    SC_PHASE("canonize_delete");
     directional_merge(false);
+    SC_PHASE("forward_merge");
     directional_merge(true);
+    SC_PHASE("backward_merge");
     path_collapse();
+    SC_PHASE("path_collapse");
     finalize_ids();
     node_level();
+    SC_PHASE("ids + levels");
+#undef SC_PHASE
 }
 
 std::string PoGraph::dump() const {
