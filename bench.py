@@ -313,7 +313,10 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
-    resident = not a.launch_mode
+    # (ranks that share ONE GPU -- the gloo rehearsal of N > 1 on a one-GPU box -- launch their levels: two processes with
+    # a resident grid each on one GPU get context-switched against each other, and the switch of workgroups that hold a whole
+    # CU's 160 KB of LDS ended in memory faults on ROCm 7.2; one rank per GPU, the real layout, has the GPU to itself)
+    resident = not a.launch_mode and not (world > 1 and backend != "nccl")
     mode = "resident level workers (one workgroup per region slot takes its levels from a host-mapped mailbox)" if resident else \
         "one launch per level (level server, batches on shared streams)"
 

@@ -13,6 +13,7 @@
 // Levels of different regions that need the same kernel leave as one grid on one of a few shared launch streams, so
 // that a hundred regions in flight need no more hardware queues than the GPU runs side by side.
 #include <hip/hip_runtime.h>
+#include <malloc.h>
 
 #include <atomic>
 #include <chrono>
@@ -365,6 +366,8 @@ struct Worker {
                                       // for the region's set-up (Ctx::lease_arena), handed back when its copies have landed
     PinnedArena passthrough;          // on = false
     DevBuf t_ref, t_pos, t_seqoff, t_seq, t_cigoff, t_cigop, t_ciglen, t_lut, t_tabs, t_pool, t_pool2;
+    FlatGraph flat;                   // the level-major arrays of the region being set up / walked
+    std::vector<int> ent_qoff_buf;
     bool setup_held = false;          // this region holds one of the context's set-up places
     std::vector<ld> cnt_scratch;      // [MAXS][KMAX] draws per (strain, read symbol) of the level just sampled
 
@@ -863,7 +866,8 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         total_copies = qo;
     }
     // prefix of copy numbers inside each level
-    std::vector<int> ent_qoff(f.ent_rid.size(), 0);
+    std::vector<int>& ent_qoff = ent_qoff_buf;                           // (the slot's: reused from region to region)
+    ent_qoff.assign(f.ent_rid.size(), 0);
     int max_level_entries = n_reads, max_level_q = 0;
     for (int l = 0; l < f.n_levels; l++) {
         int qo = 0;
@@ -1450,7 +1454,8 @@ void Worker::process(Job& job) {
     PoGraph g(job.ref, job.reads, msa, thr);
     job.stats.msa_calls = g.msa_calls;
     if (job.params.graph_only || job.params.want_graph) job.graph_dump = g.dump();      // -G text, PartialOrderGraph.cpp:318-337
-    FlatGraph f;
+    FlatGraph& f = flat;               // (the slot's arrays, reused from region to region)
+    f.reset();
     flatten(g, (int)job.reads.size(), f);
     job.stats.n_nodes = f.n_nodes; job.stats.n_levels = f.n_levels; job.stats.n_unique_reads = (int)job.reads.size();
     long copies = 0;
@@ -1519,6 +1524,18 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SC_ERR_NO_DEVICE;   // kernels are built for gfx950 only
     if (hipSetDevice(device) != hipSuccess) return SC_ERR_HIP;
     if (init_kernels() != 0) return SC_ERR_HIP;
+    {
+        // A region builds its graph out of ~10^5 small allocations and a few of tens of megabytes; handed back to the system
+        // and mapped again for every region they cost their size in page faults.  Keep freed memory in the process.
+        static std::once_flag once;
+        std::call_once(once, [] {
+            const char* e = getenv("SC_MALLOC_TUNE");
+            if (e && atoi(e) == 0) return;
+            mallopt(M_MMAP_THRESHOLD, 32 << 20);
+            mallopt(M_TRIM_THRESHOLD, 1 << 30);
+            mallopt(M_TOP_PAD, 64 << 20);
+        });
+    }
     sc_ctx* h = new sc_ctx();
     Ctx* ctx = &h->c;
     ctx->device = device;

@@ -769,7 +769,9 @@ void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>&
             if (e.force || (!linking(a, b) && !(e.check_ne && a == b))) add_edge(a, b);
         }
     }
-    // pools of the backbone / sibling nodes, in read order
+    // pools of the backbone / sibling nodes, in read order (a million entries: copy numbers from a compact array, written by index)
+    std::vector<int> copies((size_t)n);
+    for (int r = 0; r < n; r++) copies[(size_t)r] = R[r].cn;
     for (int i = 0; i < glen; i++)
         for (int c = 0; c < 8; c++) {
             const int cls = i * 8 + c;
@@ -777,9 +779,12 @@ void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>&
             const int w = class_node[cls];
             if (w < 0) throw std::runtime_error("class without a node");
             auto& pool = nodes[w].pool;
-            pool.reserve((size_t)T.count[cls]);
             const int lab = intern(std::string(1, T.sym[c]));
-            for (int x = T.off[cls]; x < T.off[cls + 1]; x++) pool.push_back({T.pool[x], R[T.pool[x]].cn, lab});
+            const size_t at = pool.size(), cnt = (size_t)(T.off[cls + 1] - T.off[cls]);
+            pool.resize(at + cnt);
+            PoolEnt* dst = pool.data() + at;
+            const int* src = T.pool.data() + T.off[cls];
+            for (size_t x = 0; x < cnt; x++) dst[x] = PoolEnt{src[x], copies[(size_t)src[x]], lab};
         }
 }
 
@@ -855,7 +860,13 @@ std::string PoGraph::dump() const {
 
 // ---------------------------------------------------------------------------
 void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
-    (void)n_reads;
+#ifdef SC_GRAPH_TIMING
+    auto now_ = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tp_ = now_();
+#define SC_PHASE(name) do { const double t_ = now_(); fprintf(stderr, "  flatten phase %-16s %.2f ms\n", name, t_ - tp_); tp_ = t_; } while (0)
+#else
+#define SC_PHASE(name) do {} while (0)
+#endif
     static const char alpha[6] = {'A', 'C', 'G', 'T', '-', '='};
     f.sym.assign(alpha, alpha + 6);
     f.K = 6;
@@ -880,9 +891,7 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
         n_pool += x.pool.size(); n_out += x.out.size(); n_lab += x.lab.size();
         (void)n_lab;                                             // read labels are stored once each (below)
     }
-    f.pool_rid.reserve(n_pool); f.pool_cn.reserve(n_pool); f.out_node.reserve(n_out); f.labels.reserve(n_lab);
-    f.ent_rid.reserve(n_pool); f.ent_cn.reserve(n_pool); f.ent_node.reserve(n_pool); f.ent_lab_off.reserve(n_pool);
-    f.ent_lab_len.reserve(n_pool); f.ent_first.reserve(n_pool);
+    f.pool_rid.resize(n_pool); f.pool_cn.resize(n_pool); f.out_node.reserve(n_out); f.labels.reserve(n_lab);
     for (int a = 0; a < f.n_nodes; a++) {
         const GNode& x = g.nodes[alive[a]];
         f.node_label_str[a] = x.lab;
@@ -895,22 +904,35 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
         for (int o : x.out) f.out_node.push_back(g.nodes[o].id);
         f.pool_ptr[a + 1] = f.pool_ptr[a] + (int)x.pool.size();
         int prev = -1;
+        int* pr = f.pool_rid.data() + f.pool_ptr[a]; int* pc = f.pool_cn.data() + f.pool_ptr[a];
+        size_t k = 0;
         for (const auto& e : x.pool) {
-            f.pool_rid.push_back(e.rid); f.pool_cn.push_back(e.cn);
+            pr[k] = e.rid; pc[k] = e.cn; k++;
             if (e.rid < prev) f.pools_sorted = false;
             prev = e.rid;
         }
     }
     f.out_support.assign(f.out_node.size(), 0);
+    SC_PHASE("nodes + pools");
 
-    // level walk, NonparametricClustering.cpp:284-334 and :556-575
+    // level walk, NonparametricClustering.cpp:284-334 and :556-575.  A million entries per region: the arrays grow a node's
+    // pool at a time and are written by index (this loop was more than half of a region's set-up on the host).
     std::vector<int> level_node{0}, sub;
-    std::vector<int> visited(f.n_nodes, -1), seen_rid_level;
+    std::vector<int> visited(f.n_nodes, -1);
     int level = 0;
     f.level_node_ptr.push_back(0);
     f.level_ent_ptr.push_back(0);
-    std::vector<int> rid_stamp;
-    std::vector<int> lab_off(g.labtab.size(), -1);
+    std::vector<int> rid_stamp((size_t)std::max(n_reads, 1), -1);
+    std::vector<int> lab_off(g.labtab.size(), -1), lab_len(g.labtab.size(), 0);
+    for (size_t i = 0; i < g.labtab.size(); i++) lab_len[i] = (int)g.labtab[i].size();
+    size_t ne = 0;                                              // entries so far
+    auto grow = [&](size_t n) {
+        if (n <= f.ent_rid.size()) return;
+        const size_t cap = std::max(n, f.ent_rid.size() + f.ent_rid.size() / 2 + 1024);
+        f.ent_rid.resize(cap); f.ent_cn.resize(cap); f.ent_node.resize(cap); f.ent_lab_off.resize(cap); f.ent_lab_len.resize(cap);
+        f.ent_first.resize(cap);
+    };
+    grow(n_pool + 16);
     while (!level_node.empty()) {
         int lrc = 0, end_pos = -1;
         for (size_t qi = 0; qi < level_node.size(); qi++) {
@@ -921,24 +943,29 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
             } else if (f.node_is_end[a]) {
                 end_pos = (int)qi;
             } else {
+                grow(ne + x.pool.size());
+                int* er = f.ent_rid.data() + ne; int* ec = f.ent_cn.data() + ne; int* en = f.ent_node.data() + ne;
+                int* eo = f.ent_lab_off.data() + ne; int* el = f.ent_lab_len.data() + ne; uint8_t* ef = f.ent_first.data() + ne;
+                size_t k = 0;
                 for (const auto& e : x.pool) {
-                    f.ent_rid.push_back(e.rid); f.ent_cn.push_back(e.cn);
-                    f.ent_node.push_back(a);
+                    er[k] = e.rid; ec[k] = e.cn; en[k] = a;
                     // a label is coded where an entry first carries it (symbol codes are handed out in the order the
                     // entries are walked) and shared by every later entry
-                    if (lab_off[(size_t)e.lab] < 0) {
-                        lab_off[(size_t)e.lab] = (int)f.labels.size();
+                    int lo = lab_off[(size_t)e.lab];
+                    if (lo < 0) {
+                        lo = lab_off[(size_t)e.lab] = (int)f.labels.size();
                         for (char c : g.labtab[(size_t)e.lab]) f.labels.push_back(code(c));
                     }
-                    f.ent_lab_off.push_back(lab_off[(size_t)e.lab]);
-                    f.ent_lab_len.push_back((int)g.labtab[(size_t)e.lab].size());
-                    if ((int)rid_stamp.size() <= e.rid) rid_stamp.resize((size_t)e.rid + 1, -1);
-                    f.ent_first.push_back(rid_stamp[e.rid] != level);
-                    rid_stamp[e.rid] = level;
+                    eo[k] = lo; el[k] = lab_len[(size_t)e.lab];
+                    if ((size_t)e.rid >= rid_stamp.size()) rid_stamp.resize((size_t)e.rid + 1, -1);
+                    ef[k] = rid_stamp[(size_t)e.rid] != level;
+                    rid_stamp[(size_t)e.rid] = level;
                     lrc += e.cn;
+                    k++;
                     // (a single-character strain label against a multi-character read label is modelled on the
                     // device: the reference looks up the never-set key sub_count[(c, "multi")] -> log 0, k_level)
                 }
+                ne += k;
             }
             for (int o : x.out) {
                 int b = g.nodes[o].id;
@@ -946,7 +973,7 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
             }
         }
         f.level_node_ptr.push_back((int)f.level_nodes.size());
-        f.level_ent_ptr.push_back((int)f.ent_rid.size());
+        f.level_ent_ptr.push_back((int)ne);
         f.level_read_count.push_back(lrc);
         f.level_has_end.push_back(end_pos >= 0);
         f.level_end_pos.push_back(end_pos);
@@ -954,6 +981,9 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
         level_node.swap(sub);
         sub.clear();
     }
+    f.ent_rid.resize(ne); f.ent_cn.resize(ne); f.ent_node.resize(ne); f.ent_lab_off.resize(ne); f.ent_lab_len.resize(ne); f.ent_first.resize(ne);
+    SC_PHASE("level walk");
+#undef SC_PHASE
     f.n_levels = level;
     if (f.K > 16 && f.unsupported.empty()) f.unsupported = "more than 16 distinct symbols in node/read labels";
 }

@@ -153,6 +153,19 @@ struct FlatGraph {
     std::vector<int> pool_ptr, pool_rid, pool_cn;
     bool pools_sorted = true;
     std::string unsupported;                       // non-empty: graph shape the device path does not model
+
+    // Empties every array and keeps its memory: a region slot flattens one region after the other, and 30 MB of freshly
+    // mapped pages per region cost as much in page faults as filling them.
+    void reset() {
+        sym.clear(); K = 6; code_N = -1; n_nodes = 0;
+        node_lab_off.clear(); node_lab_len.clear(); labels.clear(); node_label_str.clear(); node_is_end.clear();
+        out_ptr.clear(); out_node.clear(); out_support.clear();
+        n_levels = 0; level_node_ptr.clear(); level_nodes.clear(); level_ent_ptr.clear();
+        ent_rid.clear(); ent_cn.clear(); ent_lab_off.clear(); ent_lab_len.clear(); ent_node.clear(); ent_first.clear();
+        level_read_count.clear(); level_has_end.clear(); level_end_pos.clear();
+        pool_ptr.clear(); pool_rid.clear(); pool_cn.clear();
+        pools_sorted = true; unsupported.clear();
+    }
 };
 
 void flatten(const PoGraph& g, int n_reads, FlatGraph& f);
