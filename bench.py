@@ -403,15 +403,14 @@ def main():
             os.makedirs(ds, exist_ok=True)
             base = shape_regions(ds, a.sat_distinct, 1000 + rank * a.sat_distinct, a.reads, a.glen, a.strains)
             fence()
-            t1 = time.time()
-            mine_sat = run_in_flight(local, base, a.streams, a.sat_rounds, resident, a.reads)
+            mine_sat = run_in_flight(local, base, a.streams, a.sat_rounds, resident, a.reads)      # (warm pass, then the timed pass)
             fence()
-            dts = max_over_ranks(time.time() - t1)
+            dts = max_over_ranks(mine_sat["seconds"])
             busy_min = -max_over_ranks(-mine_sat["busy_cus"])
             sat = {"workload": "%d ranks x %d regions of the configs[1] shape (%d distinct data sets per rank, seeds 1000 + %d * rank ...), %d in flight per GPU" % (
                        world, mine_sat["regions"], a.sat_distinct, a.sat_distinct, a.streams),
                    "scaling": "weak", "value": sum_over_ranks(mine_sat["regions"] * a.reads) / dts, "unit": "reads/s",
-                   "seconds_max_over_ranks_incl_warm_pass": dts, "rank0": mine_sat, "min_busy_cus_over_ranks": busy_min}
+                   "seconds_max_over_ranks": dts, "rank0": mine_sat, "min_busy_cus_over_ranks": busy_min}
         if rank == 0:
             line = {"metric": "reads/sec into POA (150bp, ~1.5k-node graph)", "value": n_total * a.steps / dt, "unit": "reads/s",
                     "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
