@@ -1018,6 +1018,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
 
     // where the host's time between two levels goes (sc_stats.host_us): [0] parameters of the level (log tables, the
     // host-mapped block), [1] results of the level into the candidates' models, pruning, [2] extension of the candidates
+    int la_cache[MAXS];
     double host_acc[3] = {0, 0, 0};
     double t_mark = now_ms();
     auto lap = [&](int k) { const double t = now_ms(); host_acc[k] += t - t_mark; t_mark = t; };
@@ -1043,6 +1044,18 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 seen[r >> 6] |= 1ull << (r & 63);
             }
         }
+        // The region comes back to cold caches (hundreds of other regions have used this core since its last level): what the
+        // loops below touch per candidate -- its node's label, its model's header and log table -- is asked for up front, all
+        // candidates at once, instead of one miss after the other.
+        for (int s = 0; s < S; s++) {
+            const int nd = sv[s].node;
+            if (nd >= 0) { __builtin_prefetch(&f.node_lab_off[(size_t)nd]); __builtin_prefetch(&f.node_lab_len[(size_t)nd]); }
+            if (do_update) {
+                const Model& hm = models[(size_t)sv[s].model];
+                __builtin_prefetch(&hm.dirty); __builtin_prefetch(&hm.stale[0]);
+                for (int o = 0; o < K * K; o += 8) __builtin_prefetch(&hm.lpc[o]);
+            }
+        }
         ld za = 0;
         for (int s = 0; s < S; s++) za += sv[s].abundance;                 // normalize(), :10-15
         for (int s = 0; s < S; s++) {
@@ -1050,6 +1063,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             sp.slot = sv[s].slot;
             sp.lab_off = sv[s].node >= 0 ? f.node_lab_off[sv[s].node] : 0;
             sp.lab_len = sv[s].node >= 0 ? f.node_lab_len[sv[s].node] : 0;
+            la_cache[s] = (sp.lab_len == 1) ? (int)f.labels[(size_t)sp.lab_off] : -1;       // the candidate's symbol, for the update after the level
             sp.pad = 0;
             sp.a0 = (double)sv[s].abundance;
             sp.logpri = (mode == MODE_HARD) ? (double)logl(sv[s].abundance / za) : 0.0;      // the sampler takes a0 itself
@@ -1231,6 +1245,14 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 for (int s = 0; s < S; s++) prior[s] = level_strains[last[s]].abundance;
                 run_level(MODE_SAMPLE, e0, e1, Q, n, true, level_strains, has_dups, any_multi);
                 ld (*cnt)[KMAX] = reinterpret_cast<ld (*)[KMAX]>(cnt_scratch.data());     // (not thread_local: the fiber changes threads)
+                for (int s = 0; s < S; s++) {                      // (cold caches: see run_level)
+                    const Model& m_ = models[(size_t)level_strains[s].model];
+                    __builtin_prefetch(&Rh->cnt[s * KMAX]);
+                    if ((s & 15) == 0) __builtin_prefetch(&Rh->kdraw[s]);
+                    __builtin_prefetch(&m_.comp[0]); __builtin_prefetch(&m_.comp[4]); __builtin_prefetch(&m_.stale[0]);
+                    const int la = la_cache[s];
+                    if (la >= 0 && la < K) { __builtin_prefetch(&m_.sub[la * K]); __builtin_prefetch(&m_.sub[la * K + 4]); }
+                }
                 for (int s = 0; s < S; s++) for (int b = 0; b < K; b++) cnt[s][b] = 0;
                 if (S == 1 || n <= 0) {
                     // a single weight consumes no random numbers (libstdc++ discrete_distribution)
@@ -1257,9 +1279,9 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                     Model& m_ = models[(size_t)st_.model];
                     st_.abundance += a[s];                                   // update_model, Strain.cpp:106-125
                     unsigned changed = 0;
-                    if (f.node_lab_len[st_.node] == 1) {
-                        const int la = f.labels[f.node_lab_off[st_.node]];
-                        if (la < K) {
+                    {
+                        const int la = la_cache[s];                          // the symbol of the candidate's node (single-symbol labels only)
+                        if (la >= 0 && la < K) {
                             for (int b = 0; b < K; b++)
                                 if (cnt[s][b] > 0) { m_.sub[la * K + b] += cnt[s][b] / n; m_.stale[la] |= (uint16_t)(1u << b); }
                             m_.dirty |= 1u << la;
@@ -1284,6 +1306,13 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             } else {
                 // hard_clustering, :17-125
                 run_level(MODE_HARD, e0, e1, Q, 0, true, level_strains, has_dups, any_multi);
+                for (int s = 0; s < S; s++) {                      // (cold caches: see run_level)
+                    const Model& m_ = models[(size_t)level_strains[s].model];
+                    for (int o = 0; o < K * K; o += 8) __builtin_prefetch(&Rh->subst[(size_t)s * K * K + o]);
+                    for (int o = 0; o < K * K; o += 4) __builtin_prefetch(&m_.sub[o]);
+                    __builtin_prefetch(&m_.comp[0]); __builtin_prefetch(&m_.comp[4]); __builtin_prefetch(&m_.stale[0]);
+                    if ((s & 7) == 0) __builtin_prefetch(&Rh->abund[s]);
+                }
                 for (int s = 0; s < S; s++) {
                     HStrain& st_ = level_strains[s];
                     Model& m_ = models[(size_t)st_.model];
@@ -1309,6 +1338,11 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         branching = false;
         struct Cand { int parent; int node; ld abundance; };
         std::vector<Cand> cands;
+        for (const HStrain& s : level_strains) __builtin_prefetch(&f.out_ptr[(size_t)s.node]);
+        for (const HStrain& s : level_strains) {
+            const int ob = f.out_ptr[(size_t)s.node];
+            __builtin_prefetch(&f.out_node[(size_t)ob]); __builtin_prefetch(&f.out_support[(size_t)ob]);
+        }
         for (int si = 0; si < (int)level_strains.size(); si++) {
             const HStrain& s = level_strains[si];
             const int v = s.node;
