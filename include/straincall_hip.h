@@ -81,20 +81,31 @@ typedef struct sc_stats {
     double setup_ms;          /* the part of cluster_ms before the first level: uploads of the level-major arrays, edge support */
     double queue_ms;          /* from sc_roi_submit until a slot took the region */
     double place_ms;          /* the part of graph_ms spent waiting for one of the context's set-up places */
+    double mailbox_ms;        /* set-up done, waiting for a resident workgroup to fall free (the part of cluster_ms after setup_ms) */
     double host_us[3];        /* host work between the levels, summed over the walk: [0] the level's parameters (log tables into the
                                * host-mapped block), [1] its results into the candidates' models + pruning, [2] candidate extension */
+    double wake_us[2];        /* with several regions in flight, summed over the walk: [0] handing the levels to the level server, [1] from
+                               * the server seeing a level's stamp until the region's fiber runs again */
     long kind_levels[17];     /* levels served by each variant of the level kernel: [0] no sampler (k_level); [1 + 2 * (NB - 1) + L]
                                * the sampler for NB = ceil(candidates / 16) register blocks, L = 1 weight rows in LDS, 0 in HBM */
 } sc_stats;
 
-/* Replaces process start-up; `device` is a HIP ordinal, `stream_count` the number
- * of regions in flight.  Fails with SC_ERR_NO_DEVICE when there is no GPU. */
+/* Replaces process start-up; `device` is a HIP ordinal, `stream_count` the number of regions that walk their levels at a
+ * time (with several, on resident level workers: at most 224 of them, and the context sets up to a quarter more regions up
+ * meanwhile, so that a workgroup that finishes a region finds the next one ready).  Fails with SC_ERR_NO_DEVICE when there
+ * is no GPU. */
 int sc_ctx_create(int device, int stream_count, sc_ctx** ctx_out);
 void sc_ctx_destroy(sc_ctx* ctx);
 const char* sc_last_error(sc_ctx* ctx);
 /* The message of one region (sc_last_error holds the context's latest, which may be another region's when several
  * fail side by side).  Valid until sc_roi_release. */
 const char* sc_roi_error(sc_ctx* ctx, int handle);
+/* Binds the calling thread, and the threads it starts afterwards, to the CPUs next to GPU `device` (local_cpulist of its
+ * PCI device; what `numactl --cpunodebind` does for a rank).  Returns the number of CPUs, 0 when nothing was changed (topology
+ * unknown, no such device, SC_NUMA_BIND=0).  sc_ctx_create places the context's own threads and host memory the same way
+ * without moving its caller.  (No counterpart in the reference: rambl.py:190-194 leaves placement to the OS.) */
+int sc_host_bind(int device);
+
 /* Host threads a context with `stream_count` regions in flight starts: out[0] executor threads (they run the regions'
  * fibers), out[1] the level server (0 or 1), out[2] threads sc_aln_open inflates BGZF members on.  `cpus` = CPUs of the
  * host share (0: the cgroup quota / affinity mask of the process), divided by `local_world` ranks sharing it (0: the

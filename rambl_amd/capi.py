@@ -24,10 +24,10 @@ class ScStats(C.Structure):
     _fields_ = [("graph_ms", C.c_double), ("cluster_ms", C.c_double), ("sampler_kernel_ms", C.c_double),
                 ("sampler_launches", C.c_long), ("sampler_read_copies", C.c_long), ("level_launches", C.c_long), ("draws", C.c_long),
                 ("slow_draws", C.c_long), ("exact_draws", C.c_long), ("sampler_strains", C.c_long), ("chain_passes", C.c_long), ("chain_cycles", C.c_long), ("chain_wall_ticks", C.c_long), ("level_kernel_ticks", C.c_long), ("sampler_level_ticks", C.c_long), ("xcd_levels", C.c_long * 8), ("msa_calls", C.c_long), ("n_nodes", C.c_int), ("n_levels", C.c_int),
-                ("n_unique_reads", C.c_int), ("n_read_copies", C.c_long), ("setup_ms", C.c_double), ("queue_ms", C.c_double), ("place_ms", C.c_double), ("host_us", C.c_double * 3), ("kind_levels", C.c_long * 17)]
+                ("n_unique_reads", C.c_int), ("n_read_copies", C.c_long), ("setup_ms", C.c_double), ("queue_ms", C.c_double), ("place_ms", C.c_double), ("mailbox_ms", C.c_double), ("host_us", C.c_double * 3), ("wake_us", C.c_double * 2), ("kind_levels", C.c_long * 17)]
 
     def as_dict(self):
-        return {k: (list(getattr(self, k)) if k in ("xcd_levels", "kind_levels", "host_us") else getattr(self, k)) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k in ("xcd_levels", "kind_levels", "host_us", "wake_us") else getattr(self, k)) for k, _ in self._fields_}
 
 
 class StrainCallError(RuntimeError):
@@ -51,6 +51,8 @@ def load_library():
     lib.sc_roi_error.restype = cp
     lib.sc_host_plan.argtypes = [C.c_int, C.c_int, C.c_double, ip]
     lib.sc_host_plan.restype = C.c_int
+    lib.sc_host_bind.argtypes = [C.c_int]
+    lib.sc_host_bind.restype = C.c_int
     lib.sc_roi_submit.argtypes = [vp, cp, C.c_int, ip, cp, ip, cp, ip, ip, ip, ip, C.c_int, C.POINTER(ScParams), ip]
     lib.sc_roi_wait.argtypes = [vp, C.c_int]
     lib.sc_roi_result.argtypes = [vp, C.c_int, C.c_char_p, C.c_long, ip, C.POINTER(C.c_double), C.c_int, ip]
@@ -86,7 +88,7 @@ def load_library():
     return lib
 
 
-EXPORTS = ["sc_ctx_create", "sc_ctx_destroy", "sc_last_error", "sc_roi_error", "sc_host_plan", "sc_roi_submit", "sc_roi_wait", "sc_roi_result",
+EXPORTS = ["sc_ctx_create", "sc_ctx_destroy", "sc_last_error", "sc_roi_error", "sc_host_plan", "sc_host_bind", "sc_roi_submit", "sc_roi_wait", "sc_roi_result",
            "sc_roi_graph_dump", "sc_roi_trace", "sc_roi_stats", "sc_roi_release", "sc_roi_edge_support", "sc_msa_align",
            "sc_roi_thread_tables", "sc_aln_open", "sc_aln_open_filtered", "sc_aln_close", "sc_aln_error", "sc_aln_records", "sc_aln_ref_stats", "sc_aln_pileup_flags",
            "sc_aln_load_reads", "sc_reads_get", "sc_reads_free", "sc_depth_scan", "sc_depth_scan_runs"]
@@ -104,6 +106,12 @@ def _pack(strings):
         n += len(s)
     off[len(strings)] = n
     return "".join(strings).encode("ascii"), off
+
+
+def host_bind(device=0):
+    """This process's main thread (and every thread started after the call) onto the CPUs next to GPU `device`; the number of
+    CPUs, 0 when nothing was changed."""
+    return int(lib().sc_host_bind(int(device)))
 
 
 def host_plan(streams, local_world=0, cpus=0.0):

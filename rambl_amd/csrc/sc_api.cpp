@@ -250,22 +250,28 @@ struct Ctx {
     std::atomic<int> fibers_left{0};
     // Regions being set up (graph construction: tens of milliseconds of one CPU each) at any one time: a part of the
     // executor threads only, so that the others stay free for the continuations of the regions in flight.
-    std::atomic<int> setups{0};
+    double t_created = 0; int n_fast = 0, n_long = 0;
+    std::atomic<long>* wake_hist = nullptr;    // SC_SERVER_LOG: wake latencies, bucket b = below 2^b us
+    std::mutex smu;                   // set-up places: regions that found none park in line (they used to go round the scheduler)
+    int setups = 0;
+    std::deque<Worker*> setup_waiters;
     int setup_limit = 1;
     bool split_exec = false;                  // the pool has threads of its own for the set-ups
-    void setup_enter();
-    void setup_leave() { setups.fetch_sub(1, std::memory_order_release); }
+    void setup_enter(Worker* w);
+    void setup_leave();
     LevelParams* P_all = nullptr;             // host-mapped blocks of all slots (one allocation each)
     LevelResult* R_all = nullptr;
     LevelParams* Pd_all = nullptr;
     std::vector<LaunchStream> lstreams;
     std::vector<hipStream_t> setup_streams;   // uploads, graph kernels: shared round-robin by the workers
     // the level server: one thread launches every level and sees every completion stamp (serve_levels)
-    std::mutex dmu;                           // guards pending, server_stop
-    std::condition_variable dcv;              // the server sleeps here while nothing is pending or in flight
+    sc::SpinLock plk;                         // guards pending (a few nanoseconds per level from every executor: never a sleeping lock)
     std::deque<LevelRequest> pending;         // requests the server has not taken yet
     std::atomic<int> n_pending{0};
-    bool server_stop = false;
+    std::mutex dmu;                           // the server sleeps here (dcv) while nothing is pending or in flight
+    std::condition_variable dcv;
+    std::atomic<bool> server_asleep{false};
+    std::atomic<bool> server_stop{false};
     std::thread server;
     void submit_level(const LevelRequest& rq);
     void serve_levels();
@@ -276,12 +282,21 @@ struct Ctx {
     // from the first level posted after an idle period until no region is in flight any more (so that a device
     // synchronisation by the caller never waits on it), or until the context goes.
     bool resident = false;
-    int res_slots = 0;
+    int res_slots = 0;                // mailboxes = workgroups of the grid: regions that can WALK at a time
+    // A region needs a mailbox only while it walks its levels; its set-up (graph, uploads) happens on a worker of its own
+    // before that.  A context has more workers than mailboxes, so the next regions are set up while every workgroup is busy,
+    // and a workgroup that finishes a region finds the next one ready (mailboxes are handed from region to region).
+    std::mutex mmu;
+    std::vector<int> free_mail;               // mailboxes nobody walks on
+    std::deque<Worker*> mail_waiters;         // regions whose set-up is done, parked until a mailbox falls free
+    std::vector<unsigned> mail_seq, mail_done;     // per mailbox: last stamp posted / seen completed
+    int acquire_mailbox(Worker* w);
+    void release_mailbox(int m);
     Mailbox* mail_h = nullptr; Mailbox* mail_d = nullptr;
     ResidentCtl* ctl_h = nullptr; ResidentCtl* ctl_d = nullptr;
     hipStream_t rstream = nullptr;
     std::mutex gen_mu;
-    int gen_state = 0;                // GEN_*
+    std::atomic<int> gen_state{0};    // GEN_*; written under gen_mu
     std::atomic<int> regions_active{0};
     long generations = 0;
     std::thread heart;                // keeps ResidentCtl::heartbeat moving while the context lives
@@ -308,6 +323,39 @@ static double cpu_budget_host() {
     if (sched_getaffinity(0, sizeof set, &set) == 0) { const int k = CPU_COUNT(&set); if (k > 0 && k < n) n = k; }
     return n > 1 ? n : 1;
 }
+// The CPUs next to a GPU: `local_cpulist` of its PCI device (the cores of the socket its root port hangs on), within what
+// the process may use.  A GPU box is a two-socket host whose scheduler moves a rank's threads over both; the level
+// mailboxes, the completion stamps and the host-mapped parameter blocks are read and written across PCIe by both sides
+// several hundred thousand times a second, and from the far socket every one of those crosses the socket link as well.
+static bool gpu_local_cpus(int device, cpu_set_t* out) {
+    const char* e = getenv("SC_NUMA_BIND");
+    if (e && atoi(e) == 0) return false;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) return false;
+    for (char* c = bdf; *c; c++) *c = (char)tolower((unsigned char)*c);
+    FILE* f = fopen((std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist").c_str(), "r");
+    if (!f) return false;
+    char line[4096] = {0};
+    const bool got = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    cpu_set_t allowed, local;
+    CPU_ZERO(&local);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    for (const char* c = line; *c && *c != '\n';) {                       // "0-63,128-191"
+        char* end = nullptr;
+        const long a = strtol(c, &end, 10);
+        if (end == c) break;
+        long b = a;
+        c = end;
+        if (*c == '-') { b = strtol(c + 1, &end, 10); c = end; }
+        for (long k = a; k <= b && k < CPU_SETSIZE; k++) if (k >= 0 && CPU_ISSET((int)k, &allowed)) CPU_SET((int)k, &local);
+        if (*c == ',') c++;
+    }
+    if (CPU_COUNT(&local) == 0) return false;
+    *out = local;
+    return true;
+}
 static int local_world_size() {
     const char* e = getenv("LOCAL_WORLD_SIZE");
     const int k = e ? atoi(e) : 1;
@@ -318,6 +366,18 @@ static int local_world_size() {
 // `local_world - 1` others (0: read LOCAL_WORLD_SIZE), given `cpus` CPUs for the host (0: the cgroup quota / affinity
 // mask): out[0] executor threads (they run the regions' fibers), out[1] the level server, out[2] ingest threads of
 // sc_aln_open.  Pure arithmetic (no device): tests/test_stage5.py checks that 8 ranks on 16 CPUs stay within them.
+// Binds the calling thread -- and every thread it starts afterwards -- to the CPUs next to GPU `device` (what a launcher does
+// with `numactl --cpunodebind` per rank).  Returns how many CPUs that is; 0 when the topology is not known, the device does not
+// exist or SC_NUMA_BIND=0: nothing is changed then.  sc_ctx_create does the same for the threads and the host memory of the
+// context itself and leaves its caller where it was.
+extern "C" int sc_host_bind(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return 0;
+    cpu_set_t local;
+    if (!sc::gpu_local_cpus(device, &local)) return 0;
+    if (sched_setaffinity(0, sizeof local, &local) != 0) return 0;
+    return CPU_COUNT(&local);
+}
 extern "C" int sc_host_plan(int stream_count, int local_world, double cpus, int* out) {
     if (!out || stream_count < 1) return SC_ERR_ARG;
     double n = cpus > 0 ? cpus : sc::cpu_budget_host();
@@ -345,6 +405,8 @@ struct Worker {
     unsigned level_want = 0;          // stamp of that level
     int cur_stream = -1;              // its launch stream (server's bookkeeping)
     std::string level_err;
+    double t_seen = 0, wake_acc[2] = {0, 0};
+    int mslot = -1;                   // the mailbox (= workgroup of the resident grid) this region walks on, -1 while it has none
     double t_posted = 0;              // when the level went into the slot's mailbox (resident workers)
     double t_batch_launched = 0;      // diagnostics: when the level's batch was launched, and its size
     int batch_n = 0;
@@ -453,6 +515,7 @@ void Ctx::serve_levels() {
     std::string dead;                          // non-empty: a launch stream has failed, every level fails from now on
     auto finish = [this](Worker* w, int state, const std::string& err) {
         w->level_err = err;
+        w->t_seen = now_ms();
         w->level_state.store(state, std::memory_order_release);
         pool->make_ready(w->fib);
     };
@@ -462,7 +525,8 @@ void Ctx::serve_levels() {
         if (!resident) return;
         for (size_t i = 0; i < flying.size();) {
             Worker* w = flying[i];
-            const unsigned ms = __atomic_load_n(&mail_h[w->slot].state, __ATOMIC_ACQUIRE);
+            if (w->mslot < 0) { ++i; continue; }
+            const unsigned ms = __atomic_load_n(&mail_h[w->mslot].state, __ATOMIC_ACQUIRE);
             const bool never = ms == 0u && now_ms() - w->t_posted > 20000.0;       // more slots than the GPU holds resident
             if (w->cur_stream >= 0 || (ms < 2u && !never) || stamped(w)) { ++i; continue; }
             flying[i] = flying.back(); flying.pop_back();
@@ -474,21 +538,38 @@ void Ctx::serve_levels() {
     unsigned loops = 0;
     unsigned idle_spins = 0;
     double t_check = now_ms();
+    const bool sweep_log = getenv("SC_SERVER_LOG") != nullptr;          // diagnostics: how long one round of the loop takes while levels fly
+    double sweep_t0 = 0, sweep_sum = 0, sweep_max = 0; long sweep_n = 0, sweep_fly = 0;
     const bool any_kind = !(getenv("SC_ANY_KIND") && atoi(getenv("SC_ANY_KIND")) == 0);
     for (;;) {
-        if (n_pending.load(std::memory_order_acquire) > 0 || (waiting.empty() && flying.empty())) {
-            std::unique_lock<std::mutex> lk(dmu);
-            if (waiting.empty() && flying.empty()) dcv.wait(lk, [&] { return server_stop || !pending.empty(); });
-            if (server_stop) break;
+        if (n_pending.load(std::memory_order_seq_cst) > 0) {
+            int took = 0;
+            plk.lock();
             while (!pending.empty()) {
                 if (pending.front().kind == KIND_POSTED) { pending.front().w->cur_stream = -1; flying.push_back(pending.front().w); }
                 else waiting.push_back(pending.front());
                 pending.pop_front();
+                took++;
             }
-            n_pending.store(0, std::memory_order_release);
+            plk.unlock();
+            n_pending.fetch_sub(took, std::memory_order_seq_cst);
+        } else if (waiting.empty() && flying.empty()) {
+            // nothing to watch: sleep until a region hands a level in (announce first, then look again: submit_level looks at
+            // the flag after it has counted its request)
+            std::unique_lock<std::mutex> lk(dmu);
+            server_asleep.store(true, std::memory_order_seq_cst);
+            if (n_pending.load(std::memory_order_seq_cst) == 0 && !server_stop.load(std::memory_order_seq_cst)) dcv.wait_for(lk, std::chrono::milliseconds(50));
+            server_asleep.store(false, std::memory_order_seq_cst);
+            if (server_stop.load(std::memory_order_seq_cst)) break;
+            continue;
         }
         if ((++loops & 0xFFFFu) == 0 && resident && now_ms() - t_check > 2000.0) { t_check = now_ms(); check_resident(); }
         bool progressed = false;
+        if (sweep_log) {
+            const double t = now_ms();
+            if (sweep_t0 > 0 && !flying.empty()) { const double d = t - sweep_t0; sweep_sum += d; sweep_max = std::max(sweep_max, d); sweep_n++; sweep_fly += (long)flying.size(); }
+            sweep_t0 = t;
+        }
         // completions
         for (size_t i = 0; i < flying.size();) {
             Worker* w = flying[i];
@@ -574,25 +655,59 @@ void Ctx::serve_levels() {
             }
         }
     }
+    if (sweep_log && sweep_n) fprintf(stderr, "level server: %ld rounds with levels flying, %.2f us each (longest %.1f us), %.1f levels flying on average\n",
+                                      sweep_n, 1e3 * sweep_sum / sweep_n, 1e3 * sweep_max, (double)sweep_fly / sweep_n);
     for (Worker* w : flying) finish(w, 3, "context destroyed");
     for (auto& rq : waiting) finish(rq.w, 3, "context destroyed");
 }
-void Ctx::setup_enter() {
-    for (;;) {
-        int n = setups.load(std::memory_order_acquire);
-        if (n < setup_limit && setups.compare_exchange_weak(n, n + 1, std::memory_order_acq_rel)) return;
-        if (FiberPool::in_fiber()) FiberPool::yield(); else std::this_thread::yield();
+void Ctx::setup_enter(Worker* w) {
+    {
+        std::lock_guard<std::mutex> lk(smu);
+        if (setups < setup_limit) { setups++; return; }
+        setup_waiters.push_back(w);
     }
+    FiberPool::park();                         // setup_leave hands its place over and makes this fiber ready
+}
+void Ctx::setup_leave() {
+    Worker* next = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(smu);
+        if (!setup_waiters.empty()) { next = setup_waiters.front(); setup_waiters.pop_front(); }
+        else setups--;
+    }
+    if (next) pool->make_ready(next->fib, split_exec);          // (a set-up: for the pool's set-up threads)
+}
+// The region's set-up is done: a mailbox to walk its levels on.  Parks until one falls free.
+int Ctx::acquire_mailbox(Worker* w) {
+    {
+        std::lock_guard<std::mutex> lk(mmu);
+        if (!free_mail.empty()) { const int m = free_mail.back(); free_mail.pop_back(); return m; }
+        w->mslot = -1;
+        mail_waiters.push_back(w);
+    }
+    FiberPool::park();                         // release_mailbox hands one over (w->mslot) and makes the fiber ready
+    return w->mslot;
+}
+void Ctx::release_mailbox(int m) {
+    Worker* next = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mmu);
+        if (!mail_waiters.empty()) { next = mail_waiters.front(); mail_waiters.pop_front(); next->mslot = m; }
+        else free_mail.push_back(m);
+    }
+    if (next) pool->make_ready(next->fib);
 }
 // A level is about to be posted to slot w->slot: make sure a generation of the resident grid is there to take it.
 void Ctx::resident_ensure(Worker* w) {
+    // the ordinary case, once per level from every executor, takes no lock: the generation runs and the mailbox's workgroup is there
+    if (gen_state.load(std::memory_order_acquire) == GEN_RUNNING && __atomic_load_n(&mail_h[w->mslot].state, __ATOMIC_ACQUIRE) < 2u) return;
     const double t0 = now_ms();
     for (;;) {
         if (now_ms() - t0 > 60000.0) throw HipError("resident level workers: the previous grid has not left after a minute");
         {
             std::lock_guard<std::mutex> lk(gen_mu);
             if (gen_state == GEN_RUNNING) {
-                if (__atomic_load_n(&mail_h[w->slot].state, __ATOMIC_ACQUIRE) < 2u) return;
+                if (__atomic_load_n(&mail_h[w->mslot].state, __ATOMIC_ACQUIRE) < 2u) return;
                 // the slot's workgroup has left although regions are in flight (the heartbeat limit): end this generation
                 __atomic_store_n(&ctl_h->stop, 1u, __ATOMIC_RELEASE);
                 gen_state = GEN_STOPPING;
@@ -604,10 +719,10 @@ void Ctx::resident_ensure(Worker* w) {
             }
             if (gen_state == GEN_STOPPED) {
                 __atomic_store_n(&ctl_h->stop, 0u, __ATOMIC_RELEASE);
-                // a workgroup starts from the last stamp its slot has completed: what is in the mailbox beyond that is new
-                for (int i = 0; i < res_slots; i++) { mail_h[i].ack = __atomic_load_n(&workers[(size_t)i]->Rh->seq, __ATOMIC_ACQUIRE); mail_h[i].state = 0; }
+                // a workgroup starts from the last stamp its mailbox has seen completed: what is in the mailbox beyond that is new
+                for (int i = 0; i < res_slots; i++) { mail_h[i].ack = __atomic_load_n(&mail_done[(size_t)i], __ATOMIC_ACQUIRE); mail_h[i].state = 0; }
                 __atomic_thread_fence(__ATOMIC_RELEASE);
-                ResidentArgs ra{mail_d, ctl_d, 300000000ull, workers[0]->Pm, workers[0]->Rd};     // 3 s of 100 MHz ticks without a heartbeat
+                ResidentArgs ra{mail_d, ctl_d, 300000000ull, workers[0]->Pm, workers[0]->Rd, (int)workers.size()};     // 3 s of 100 MHz ticks without a heartbeat
                 (void)hipGetLastError();
                 launch_resident(rstream, ra, res_slots);
                 const hipError_t le = hipGetLastError();
@@ -645,18 +760,25 @@ void Ctx::resident_shutdown() {
 }
 void Ctx::submit_level(const LevelRequest& rq) {
     rq.w->level_state.store(1, std::memory_order_release);
-    {
-        std::lock_guard<std::mutex> lk(dmu);
-        pending.push_back(rq);
-        n_pending.fetch_add(1, std::memory_order_release);
+    plk.lock();
+    pending.push_back(rq);
+    plk.unlock();
+    n_pending.fetch_add(1, std::memory_order_seq_cst);
+    if (server_asleep.load(std::memory_order_seq_cst)) {
+        { std::lock_guard<std::mutex> lk(dmu); }
+        dcv.notify_one();
     }
-    dcv.notify_one();
 }
 // The region's fiber parks until the server has seen the level's stamp (or failed the level).  The server makes the
 // fiber ready exactly once per request, so the fiber parks exactly once per request -- also when the level is already
 // done by the time it gets here (it then comes straight back).
 void Worker::wait_level() {
+    const double t_park = now_ms();
     FiberPool::park();
+    const double t_back = now_ms();
+    wake_acc[0] += t_park - t_posted;           // handing the level to the server
+    wake_acc[1] += t_back - t_seen;             // the server has seen the stamp -> this fiber runs again
+    if (ctx->wake_hist) { const double us = 1e3 * (t_back - t_seen); int b = 0; while (b < 23 && us >= (double)(1 << b)) b++; ctx->wake_hist[b].fetch_add(1, std::memory_order_relaxed); }
     const int state = level_state.load(std::memory_order_acquire);
     if (state == 3) throw HipError(level_err);
     if (state != 2) throw HipError("a region was resumed before its level was done");
@@ -947,6 +1069,17 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     // ---- level walk: from here on the region's host work is a few microseconds per level
     if (setup_held) { ctx->setup_leave(); setup_held = false; }
     job.stats.setup_ms = now_ms() - t_cluster0;
+    struct MailHold {                  // the mailbox the region walks on (resident workers): taken now, handed on when the walk ends
+        Worker* w;
+        void drop() { if (w->mslot >= 0) { const int m = w->mslot; w->mslot = -1; w->ctx->release_mailbox(m); } }
+        ~MailHold() { drop(); }
+    } mail_hold{this};
+    if (ctx->resident) {
+        const double t_m0 = now_ms();
+        mslot = ctx->acquire_mailbox(this);
+        job.stats.mailbox_ms = now_ms() - t_m0;
+        __atomic_store_n(&Rh->seq, 0u, __ATOMIC_RELEASE);       // (stamps are the mailbox's from here on: never 0)
+    }
     std::vector<HStrain> level_strains, sub_strains;
     std::vector<Model> models;                                           // pool; free entries in free_models
     std::vector<int> free_models;
@@ -1093,7 +1226,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             H.done = launch_level_grid(st, jd, H, Pd);
             sync_stream();                               // the level's kernel runs on another stream
         }
-        H.seq = ++seq;
+        H.seq = (ctx->resident && mslot >= 0) ? ++ctx->mail_seq[(size_t)mslot] : ++seq;     // (a mailbox keeps its own count: regions take turns on it)
         level_want = H.seq;
         if (timed) {
             // a fresh pair of events per sampler launch; their times are read after the walk, not between levels
@@ -1110,7 +1243,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         if (ctx->resident) {
             // the slot's resident workgroup takes the level from its mailbox: the item, then its stamp (release)
             ctx->resident_ensure(this);
-            Mailbox& mb = ctx->mail_h[slot];
+            Mailbox& mb = ctx->mail_h[mslot];
             mb.item = LevelItem{jd_dev, H, level_kind(H) | (level_lds_kb(H, K) << 8), Pm, Rd};
             __atomic_store_n(&mb.seq, H.seq, __ATOMIC_RELEASE);
             t_posted = now_ms();
@@ -1153,9 +1286,11 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 }
             }
         } else {
+            t_posted = now_ms();
             ctx->submit_level(LevelRequest{this, LevelItem{jd_dev, H, level_kind(H) | (level_lds_kb(H, K) << 8), Pm, Rd}, level_kind(H), timed});
             wait_level();
         }
+        if (ctx->resident && mslot >= 0) __atomic_store_n(&ctx->mail_done[(size_t)mslot], H.seq, __ATOMIC_RELEASE);
         t_mark = now_ms();                                   // (the wait for the level is not host work)
         level_launches++;
         if (chain) {
@@ -1420,6 +1555,11 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 a[s] = sc_add_ones(fs[s].abundance, Rh->kdraw[s]);                   // :823, one rounding per draw
             }
         }
+        // The last level is done: the mailbox goes to the next region.  What is left of this one -- its sequences, and giving
+        // back what the walk has allocated (the graph, the candidates' models: milliseconds of free()) -- is a long stretch, and
+        // those belong on the pool's set-up threads: on a continuation thread it would hold up ~100 levels of other regions.
+        mail_hold.drop();
+        if (ctx->split_exec && FiberPool::in_fiber()) FiberPool::yield();
         ld z = 0;
         for (int s = 0; s < S; s++) z += a[s];
         for (int s = 0; s < S; s++) fs[s].abundance = a[s] / z;
@@ -1445,6 +1585,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
     }
     ev_used = 0;
     for (int k = 0; k < 3; k++) job.stats.host_us[k] = 1e3 * host_acc[k];
+    for (int k = 0; k < 2; k++) { job.stats.wake_us[k] = 1e3 * wake_acc[k]; wake_acc[k] = 0; }
     job.stats.sampler_kernel_ms = sampler_ms;
     job.stats.sampler_launches = sampler_launches;
     job.stats.sampler_read_copies = sampler_copies;
@@ -1473,7 +1614,7 @@ void Worker::process(Job& job) {
     } setup{this};
     job.stats.queue_ms = t0 - job.t_submit;
     if (ctx->split_exec) FiberPool::yield();           // the set-up belongs on one of the pool's set-up threads
-    ctx->setup_enter();
+    ctx->setup_enter(this);
     setup_held = true;
     job.stats.place_ms = now_ms() - t0;
     stage = ctx->lease_arena(&passthrough);
@@ -1558,6 +1699,16 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SC_ERR_NO_DEVICE;   // kernels are built for gfx950 only
     if (hipSetDevice(device) != hipSuccess) return SC_ERR_HIP;
     if (init_kernels() != 0) return SC_ERR_HIP;
+    // the context's threads (they inherit the mask of the thread that starts them) and the host memory it allocates and first
+    // touches here: next to the GPU; the caller's own mask comes back when this function returns
+    struct Near {
+        cpu_set_t before; bool moved = false;
+        explicit Near(int dev) {
+            cpu_set_t local;
+            if (sched_getaffinity(0, sizeof before, &before) == 0 && sc::gpu_local_cpus(dev, &local)) moved = sched_setaffinity(0, sizeof local, &local) == 0;
+        }
+        ~Near() { if (moved) (void)sched_setaffinity(0, sizeof before, &before); }
+    } near{device};
     {
         // A region builds its graph out of ~10^5 small allocations and a few of tens of megabytes; handed back to the system
         // and mapped again for every region they cost their size in page faults.  Keep freed memory in the process.
@@ -1601,8 +1752,15 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         // scratch memory, and the queue's scratch holds 7 wavefronts per CU.  32 CUs stay free for the set-up kernels.
         int cap = rs ? atoi(rs) : std::max(prop.multiProcessorCount - 32, 1);
         cap = cap < 1 ? 1 : (cap > prop.multiProcessorCount ? prop.multiProcessorCount : cap);
-        if (ctx->resident && stream_count > cap) stream_count = cap;
-        ctx->res_slots = stream_count;
+        ctx->res_slots = ctx->resident ? std::min(stream_count, cap) : stream_count;
+        // workers = regions walking (one mailbox each) + regions being set up meanwhile: those the caller asks for beyond the
+        // mailboxes (stream_count above the cap) or SC_SETUP_WORKERS.  None by default: on a 16-CPU share of a host the set-ups
+        // are bounded by the CPUs, not by the workers that wait for one (measured: 0 / 28 / 56 extra, no difference beyond noise)
+        if (ctx->resident && ctx->res_slots > 1) {
+            int extra = 0;
+            if (const char* ex = getenv("SC_SETUP_WORKERS")) extra = std::max(0, atoi(ex));
+            stream_count = std::min(std::max(stream_count, ctx->res_slots + extra), 512);
+        }
     }
     if (ctx->resident) {
         // The resident grid stays in its hardware queue for as long as regions are in flight: nothing else may ever be
@@ -1663,14 +1821,17 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         return SC_ERR_HIP;
     }
     if (ctx->resident) {
-        if (hipHostMalloc((void**)&ctx->mail_h, ns * sizeof(Mailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        const size_t nm = (size_t)ctx->res_slots;
+        ctx->mail_seq.assign(nm, 0u); ctx->mail_done.assign(nm, 0u);
+        for (int m = ctx->res_slots - 1; m >= 0; m--) ctx->free_mail.push_back(m);
+        if (hipHostMalloc((void**)&ctx->mail_h, nm * sizeof(Mailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostMalloc((void**)&ctx->ctl_h, sizeof(ResidentCtl), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostGetDevicePointer((void**)&ctx->mail_d, ctx->mail_h, 0) != hipSuccess ||
             hipHostGetDevicePointer((void**)&ctx->ctl_d, ctx->ctl_h, 0) != hipSuccess) {
             sc_ctx_destroy(h);
             return SC_ERR_HIP;
         }
-        std::memset(ctx->mail_h, 0, ns * sizeof(Mailbox));
+        std::memset(ctx->mail_h, 0, nm * sizeof(Mailbox));
         std::memset(ctx->ctl_h, 0, sizeof(ResidentCtl));
         ctx->heart = std::thread([ctx] {
             while (!ctx->heart_stop.load(std::memory_order_acquire)) {
@@ -1687,6 +1848,7 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
     ctx->split_exec = n_long > 0;
     if (!getenv("SC_SETUP_LIMIT") && n_long > 0) ctx->setup_limit = 2 * n_long;      // a set-up waits for the GPU part of its time
     ctx->pool.reset(new FiberPool(plan[0], [dev] { (void)hipSetDevice(dev); }, n_long));
+    if (getenv("SC_SERVER_LOG")) { ctx->pool->set_diag(true); ctx->wake_hist = new std::atomic<long>[24](); ctx->t_created = now_ms(); ctx->n_fast = plan[0] - n_long; ctx->n_long = n_long; }
     if (stream_count > 1) ctx->server = std::thread([ctx] { ctx->serve_levels(); });
     ctx->fibers_left.store(stream_count, std::memory_order_release);
     for (auto& w : ctx->workers) {
@@ -1709,10 +1871,25 @@ void sc_ctx_destroy(sc_ctx* h) {
         // regions still queued or in flight are finished first (as the worker threads of earlier versions did)
         while (ctx->fibers_left.load(std::memory_order_acquire) > 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
-    { std::lock_guard<std::mutex> lk(ctx->dmu); ctx->server_stop = true; }
+    { std::lock_guard<std::mutex> lk(ctx->dmu); ctx->server_stop.store(true, std::memory_order_seq_cst); }
     ctx->dcv.notify_all();
     if (ctx->server.joinable()) ctx->server.join();
     if (ctx->pool) ctx->pool->shutdown();
+    if (ctx->wake_hist) {
+        // diagnostics: how busy the two kinds of executor were (time stamp counter against the wall clock of the context's
+        // life), how long their stretches inside fibers were, how long a region whose level had come back waited for one
+        fprintf(stderr, "executors: %d continuation + %d set-up threads over %.1f ms; inside fibers %.1f / %.1f Mticks\n", ctx->n_fast, ctx->n_long,
+                now_ms() - ctx->t_created, ctx->pool->busy_ticks(false) * 1e-6, ctx->pool->busy_ticks(true) * 1e-6);
+        for (int l = 0; l < 2; l++) {
+            fprintf(stderr, "  stretches on %s threads (log2 ticks: count):", l ? "set-up" : "continuation");
+            for (int b = 0; b < 40; b++) if (ctx->pool->stretch_count(l, b)) fprintf(stderr, " %d:%ld", b, ctx->pool->stretch_count(l, b));
+            fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "  wake latency (below 2^b us: count):");
+        for (int b = 0; b < 24; b++) if (ctx->wake_hist[b].load()) fprintf(stderr, " %d:%ld", b, ctx->wake_hist[b].load());
+        fprintf(stderr, "\n");
+        delete[] ctx->wake_hist; ctx->wake_hist = nullptr;
+    }
     (void)hipSetDevice(ctx->device);
     ctx->resident_shutdown();
     ctx->heart_stop.store(true, std::memory_order_release);

@@ -118,8 +118,9 @@ struct ResidentArgs {
     Mailbox* mail;               // host-mapped, [slots]
     const ResidentCtl* ctl;      // host-mapped
     unsigned long long idle_ticks;   // 100 MHz ticks without a heartbeat change after which a workgroup gives up
-    const LevelParams* P_base;   // the slots' host-mapped parameter / result blocks: slot b's item must name block b
+    const LevelParams* P_base;   // the workers' host-mapped parameter / result blocks: an item must name one of them
     LevelResult* R_base;
+    int n_blocks;
 };
 
 // Per-level results, written by the kernel into host-mapped pinned memory; `seq` last (system-scope release).

@@ -58,6 +58,22 @@ namespace sc {
 
 class FiberPool;
 
+// A lock for sections of a few nanoseconds that are entered hundreds of thousands of times a second from a handful of
+// threads (the scheduler's queues, the level server's inbox).  It never sleeps in the kernel: a mutex does when it is
+// contended, and the ~50 us until the sleeper runs again are several levels' worth of host work.
+class SpinLock {
+public:
+    void lock() {
+        for (unsigned n = 0;; n++) {
+            if (!busy_.load(std::memory_order_relaxed) && !busy_.exchange(true, std::memory_order_acquire)) return;
+            if ((n & 0xFFFu) == 0xFFFu) std::this_thread::yield(); else __builtin_ia32_pause();       // (its holder has lost its CPU)
+        }
+    }
+    void unlock() { busy_.store(false, std::memory_order_release); }
+private:
+    std::atomic<bool> busy_{false};
+};
+
 struct Fiber {
     void* sp = nullptr;                 // saved stack pointer while the fiber is not running
     void* stack = nullptr;
@@ -115,7 +131,7 @@ public:
         w[7] = (uint64_t)(uintptr_t)&FiberPool::entry;
         w[8] = 0;
         f->sp = w;
-        { std::lock_guard<std::mutex> lk(mu_); all_.push_back(f); }
+        { std::lock_guard<std::mutex> lk(sleep_mu_); all_.push_back(f); }
         return f;
     }
 
@@ -125,16 +141,20 @@ public:
     // `later`: behind every fiber that was made ready the ordinary way -- for long, CPU-bound stretches (the set-up of
     // a new region) that must not delay the short continuations of the regions whose levels are coming back.
     void make_ready(Fiber* f, bool later = false) {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            (later ? later_ : ready_).push_back(f);
+        qlock();
+        (later ? later_ : ready_).push_back(f);
+        qunlock();
+        // (the queue is filled before its counter rises: whoever sees the counter finds the fiber)
+        if (later) {
+            n_later_.fetch_add(1, std::memory_order_seq_cst);
+            if (split_) { if (long_sleepers_.load(std::memory_order_seq_cst) > 0) wake(cv_long_); return; }
+            if (sleepers_.load(std::memory_order_seq_cst) > 0 && spinners_.load(std::memory_order_acquire) == 0) wake(cv_);
+            return;
         }
-        if (!later) n_front_.fetch_add(1, std::memory_order_release);
-        const int nr = n_ready_.fetch_add(1, std::memory_order_release) + 1;
-        if (later && split_) { if (long_sleepers_.load(std::memory_order_acquire) > 0) cv_long_.notify_one(); return; }
+        const int nf = n_front_.fetch_add(1, std::memory_order_seq_cst) + 1;
         // a spinning executor sees the counter at once; a sleeping one is woken only when no spinner is there to take this
         // fiber (a futex call per level would cost the level server more than the level's own bookkeeping)
-        if (sleepers_.load(std::memory_order_acquire) > 0 && nr > spinners_.load(std::memory_order_acquire)) cv_.notify_one();
+        if (sleepers_.load(std::memory_order_seq_cst) > 0 && nf > spinners_.load(std::memory_order_acquire)) wake(cv_);
     }
 
     // From inside a fiber: give the thread back until somebody calls make_ready(this fiber).
@@ -151,6 +171,8 @@ public:
     // fibers made ready the ordinary way and not taken yet (a fiber that polls for something may sleep instead of yielding
     // while this is zero)
     int ready_now() const { return n_front_.load(std::memory_order_acquire); }
+    // fibers waiting in the `later` queue (regions in set-up that have yielded)
+    int later_now() const { return n_later_.load(std::memory_order_acquire); }
     static Fiber*& current() { return tl_current(); }
     static bool in_fiber() { return tl_current() != nullptr; }
 
@@ -158,9 +180,9 @@ public:
     // (their stacks are unmapped): the owner makes its fibers finish first.
     void shutdown() {
         {
-            std::lock_guard<std::mutex> lk(mu_);
-            if (stop_) return;
-            stop_ = true;
+            std::lock_guard<std::mutex> lk(sleep_mu_);
+            if (stop_.load()) return;
+            stop_.store(true);
         }
         cv_.notify_all();
         cv_long_.notify_all();
@@ -170,6 +192,11 @@ public:
     }
 
     // diagnostics / tests
+    void set_diag(bool on) { diag_ = on; }
+    // time stamp counter ticks the two kinds of executor have spent inside fibers, and how long the stretches were
+    // (log2 buckets of ticks)
+    uint64_t busy_ticks(bool lng) const { return (lng ? busy_long_ : busy_fast_).load(std::memory_order_relaxed); }
+    long stretch_count(bool lng, int bucket) const { return hist_[lng ? 1 : 0][bucket].load(std::memory_order_relaxed); }
     long switches() const { return switches_.load(std::memory_order_relaxed); }
     int max_running() const { return max_running_.load(std::memory_order_relaxed); }
 
@@ -190,19 +217,39 @@ private:
         sc_fiber_switch(&f->sp, *f->back);
         __builtin_trap();
     }
+    // The two queues are touched for a few nanoseconds at a time by the level server (a fiber per finished level) and by
+    // every executor: a lock that never sleeps.  (They were under the mutex the executors also sleep on: eight executors
+    // asking it for work at once put each other -- and the level server -- to sleep in the kernel, ~50 us per level at
+    // 224 regions in flight.)
+    void qlock() { qlk_.lock(); }
+    void qunlock() { qlk_.unlock(); }
+    // Wakes one sleeping executor.  Passing through the sleepers' mutex first: a sleeper that has announced itself and
+    // checked the counters before they rose is inside wait() by the time this notifies.
+    void wake(std::condition_variable& cv) {
+        { std::lock_guard<std::mutex> lk(sleep_mu_); }
+        cv.notify_one();
+    }
+    // what a thread of this kind may take: the set-up threads take the long stretches first, the others never take them
+    // when the pool is split
+    bool has_work(bool lng) const {
+        if (n_front_.load(std::memory_order_seq_cst) > 0) return true;
+        return (lng || !split_) && n_later_.load(std::memory_order_seq_cst) > 0;
+    }
+    Fiber* take(bool lng) {
+        if (!has_work(lng)) return nullptr;
+        Fiber* f = nullptr;
+        qlock();
+        if (lng && !later_.empty()) { f = later_.front(); later_.pop_front(); n_later_.fetch_sub(1, std::memory_order_relaxed); }
+        else if (!ready_.empty()) { f = ready_.front(); ready_.pop_front(); n_front_.fetch_sub(1, std::memory_order_relaxed); }
+        else if (!lng && !split_ && !later_.empty()) { f = later_.front(); later_.pop_front(); n_later_.fetch_sub(1, std::memory_order_relaxed); }
+        qunlock();
+        return f;
+    }
     void run(bool lng) {
         if (on_start_) on_start_();
         void* self_sp = nullptr;
-        unsigned spins = 0;
         for (;;) {
-            Fiber* f = nullptr;
-            if (n_ready_.load(std::memory_order_acquire) > 0) {
-                std::lock_guard<std::mutex> lk(mu_);
-                auto take_front = [&] { f = ready_.front(); ready_.pop_front(); n_ready_.fetch_sub(1, std::memory_order_relaxed); n_front_.fetch_sub(1, std::memory_order_relaxed); };
-                auto take_later = [&] { f = later_.front(); later_.pop_front(); n_ready_.fetch_sub(1, std::memory_order_relaxed); };
-                if (lng) { if (!later_.empty()) take_later(); else if (!ready_.empty()) take_front(); }
-                else { if (!ready_.empty()) take_front(); else if (!split_ && !later_.empty()) take_later(); }
-            }
+            Fiber* f = take(lng);
             if (!f) {
                 // Nothing ready (for this kind of thread).  A rank's CPU share is a quota of CPU TIME (a GPU box hands out 16
                 // CPUs of its host as a cgroup bandwidth limit): an executor that spins spends the quota the regions'
@@ -210,23 +257,22 @@ private:
                 // up within a fraction of a microsecond); the others sleep and are woken when fibers queue up behind the spinners.
                 if (!lng && spinners_.load(std::memory_order_acquire) < max_spinners_) {
                     spinners_.fetch_add(1, std::memory_order_acq_rel);
-                    for (spins = 0; spins < 6000 && n_front_.load(std::memory_order_acquire) == 0 && (split_ || n_ready_.load(std::memory_order_acquire) == 0); spins++) __builtin_ia32_pause();
+                    for (unsigned spins = 0; spins < 6000 && !has_work(false); spins++) __builtin_ia32_pause();
                     spinners_.fetch_sub(1, std::memory_order_acq_rel);
-                    if (n_ready_.load(std::memory_order_acquire) > 0) continue;
+                    if (has_work(false)) continue;
                 }
-                std::unique_lock<std::mutex> lk(mu_);
-                auto mine = [&] { return lng ? (!later_.empty() || !ready_.empty()) : (!ready_.empty() || (!split_ && !later_.empty())); };
-                if (stop_ && !mine()) return;
-                if (!mine()) {
-                    std::atomic<int>& sl = lng ? long_sleepers_ : sleepers_;
-                    sl.fetch_add(1, std::memory_order_release);
-                    (lng ? cv_long_ : cv_).wait_for(lk, std::chrono::milliseconds(lng ? 5 : 20), [&] { return stop_ || mine(); });
-                    sl.fetch_sub(1, std::memory_order_release);
+                std::atomic<int>& sl = lng ? long_sleepers_ : sleepers_;
+                std::unique_lock<std::mutex> lk(sleep_mu_);
+                sl.fetch_add(1, std::memory_order_seq_cst);
+                if (!has_work(lng)) {
+                    if (stop_.load()) { sl.fetch_sub(1, std::memory_order_seq_cst); return; }
+                    (lng ? cv_long_ : cv_).wait_for(lk, std::chrono::milliseconds(lng ? 5 : 20));
                 }
+                sl.fetch_sub(1, std::memory_order_seq_cst);
                 continue;
             }
             // more fibers wait than spinners stand by: bring a sleeping executor in
-            if (sleepers_.load(std::memory_order_acquire) > 0 && n_front_.load(std::memory_order_acquire) > spinners_.load(std::memory_order_acquire)) cv_.notify_one();
+            if (sleepers_.load(std::memory_order_acquire) > 0 && n_front_.load(std::memory_order_acquire) > spinners_.load(std::memory_order_acquire)) wake(cv_);
             if (f->finished.load(std::memory_order_acquire)) continue;                              // (a stale entry: never resume a finished fiber)
             while (f->on_cpu.exchange(true, std::memory_order_acquire)) __builtin_ia32_pause();     // still switching out elsewhere
             const int r = running_.fetch_add(1, std::memory_order_relaxed) + 1;
@@ -234,7 +280,9 @@ private:
             while (r > m && !max_running_.compare_exchange_weak(m, r, std::memory_order_relaxed)) {}
             f->back = &self_sp;
             tl_current() = f;
+            const uint64_t c0 = diag_ ? __builtin_ia32_rdtsc() : 0;
             sc_fiber_switch(&self_sp, f->sp);
+            if (diag_) { const uint64_t d = __builtin_ia32_rdtsc() - c0; (lng ? busy_long_ : busy_fast_).fetch_add(d, std::memory_order_relaxed); int b = 0; while ((d >> b) > 1 && b < 39) b++; hist_[lng][b].fetch_add(1, std::memory_order_relaxed); }
             tl_current() = nullptr;
             running_.fetch_sub(1, std::memory_order_relaxed);
             switches_.fetch_add(1, std::memory_order_relaxed);
@@ -244,15 +292,19 @@ private:
 
     std::function<void()> on_start_;
     std::vector<std::thread> threads_;
-    std::mutex mu_;
+    std::mutex sleep_mu_;                        // the sleeping executors' (and all_'s); never held while a queue is touched
     std::condition_variable cv_, cv_long_;
+    SpinLock qlk_;                               // the queues' lock
     std::deque<Fiber*> ready_, later_;
     std::vector<Fiber*> all_;
-    std::atomic<int> n_ready_{0}, n_front_{0}, sleepers_{0}, long_sleepers_{0}, spinners_{0}, running_{0}, max_running_{0};
+    std::atomic<int> n_front_{0}, n_later_{0}, sleepers_{0}, long_sleepers_{0}, spinners_{0}, running_{0}, max_running_{0};
     int max_spinners_ = 4;
     bool split_ = false;
     std::atomic<long> switches_{0};
-    bool stop_ = false;
+    std::atomic<bool> stop_{false};
+    bool diag_ = false;
+    std::atomic<uint64_t> busy_fast_{0}, busy_long_{0};
+    std::atomic<long> hist_[2][40] = {};
 };
 
 }  // namespace sc

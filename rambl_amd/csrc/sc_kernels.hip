@@ -1102,8 +1102,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_level_resident(ResidentArgs a
                 for (int i = 0; i < 5; i++) dst[i] = src[i];
                 last = s_item.h.seq;
                 served++;
-                // an item that does not name this slot's own blocks was not written for it: leave rather than follow its pointers
-                if (s_item.P != a.P_base + blockIdx.x || s_item.R != a.R_base + blockIdx.x || s_item.job == nullptr) cmd = 2;
+                // an item that does not name one worker's pair of blocks was not written by the library: leave rather than follow its pointers
+                const long ip = s_item.P - a.P_base, ir = s_item.R - a.R_base;
+                if (ip < 0 || ip >= a.n_blocks || ir != ip || a.P_base + ip != s_item.P || s_item.job == nullptr) cmd = 2;
             }
             s_cmd = cmd;
         }

@@ -49,6 +49,8 @@ def main():
     reads = int(os.environ.get("SC_PROBE_READS", "10000"))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("SC_PROBE_QUEUES", "24"))
     from rambl_amd import capi, stage5
+    if os.environ.get("SC_PROBE_BIND") == "1":
+        print("bound to %d CPUs next to the GPU" % capi.host_bind(0), file=sys.stderr)
     # distinct data sets (seeds 21..), reused cyclically; SC_PROBE_ROUNDS x R regions pass through the context with R in
     # flight, so that the ramp at the start and the drain at the end weigh 1 / rounds (the steady state is what a node sees)
     distinct = int(os.environ.get("SC_PROBE_DISTINCT", "48"))
@@ -94,15 +96,17 @@ def main():
         rec["setup_ms"] = round(sum(s["setup_ms"] for s in stats) / n, 1)
         rec["queue_ms"] = round(sum(s["queue_ms"] for s in stats) / n, 1)
         rec["place_ms"] = round(sum(s["place_ms"] for s in stats) / n, 1)
+        rec["mailbox_ms"] = round(sum(s["mailbox_ms"] for s in stats) / n, 1)
         rec["host_us_per_level"] = [round(sum(s["host_us"][k] for s in stats) / max(sum(s["level_launches"] for s in stats), 1), 1) for k in range(3)]
+        rec["wake_us_per_level"] = [round(sum(s["wake_us"][k] for s in stats) / max(sum(s["level_launches"] for s in stats), 1), 1) for k in range(2)]
         try:
             cs1 = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
             rec["throttled_ms"] = round((int(cs1["throttled_usec"]) - int(cs0["throttled_usec"])) / 1e3, 1)
             rec["nr_throttled"] = int(cs1["nr_throttled"]) - int(cs0["nr_throttled"])
         except (OSError, KeyError, ValueError, NameError):
             pass
-        rec["knobs"] = {k: os.environ[k] for k in ("SC_EXEC_THREADS", "SC_SETUP_LIMIT", "SC_RESIDENT_SLOTS") if k in os.environ}
-        rec["gap_us_per_level"] = round(1e3 * (rec["cluster_ms"] - rec["setup_ms"] - rec["level_kernel_ms"]) / max(rec["levels"], 1), 1)
+        rec["knobs"] = {k: os.environ[k] for k in ("SC_EXEC_THREADS", "SC_EXEC_LONG", "SC_EXEC_SPINNERS", "SC_SETUP_LIMIT", "SC_SETUP_WORKERS", "SC_RESIDENT_SLOTS", "SC_NUMA_BIND", "SC_PROBE_BIND") if k in os.environ}
+        rec["gap_us_per_level"] = round(1e3 * (rec["cluster_ms"] - rec["setup_ms"] - rec["mailbox_ms"] - rec["level_kernel_ms"]) / max(rec["levels"], 1), 1)
         # share of the GPU's 256 CUs that held a level workgroup, averaged over the run
         rec["cu_busy_frac"] = round(sum(s["level_kernel_ticks"] for s in stats) / 1e5 / 1e3 / (256 * dt), 3)
         print(json.dumps(rec), flush=True)
