@@ -581,11 +581,15 @@ __device__ __forceinline__ void phase_update(const JD& job, const LevelHdr& h, c
                                              const double* s_lpt, int tid, int nt) {
     const int S = h.S, K = job.K, K2 = K * K, e0 = h.e0, Rn = h.e1 - h.e0;
     const long stride = job.ll_stride;
-    for (int r = tid; r < Rn; r += nt) {
-        const int e = e0 + r;
-        job.isnew[r] = (job.ent_first[e] && !job.has[job.ent_rid[e]]) ? 1 : 0;
+    const bool plain_labels = !h.has_dups && !h.any_multi && !(h.done & LV_ITEMS_DONE);
+    if (!plain_labels) {
+        // (the walk over multi-symbol labels below and in the soft update reads this; the usual level finds it on the way)
+        for (int r = tid; r < Rn; r += nt) {
+            const int e = e0 + r;
+            job.isnew[r] = (job.ent_first[e] && !job.has[job.ent_rid[e]]) ? 1 : 0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int codeN = job.code_N;
     auto item = [&](int s, int r) {
         const int e = e0 + r;
@@ -634,30 +638,37 @@ __device__ __forceinline__ void phase_update(const JD& job, const LevelHdr& h, c
         // single-symbol labels everywhere (the usual level): a thread takes a read of the level and walks the strains
         // eight at a time, so eight independent row cells are in flight per thread and neighbouring threads (reads
         // sorted by position: neighbouring ids) touch neighbouring cells of each row
-        constexpr int U = 8;
+        // An item is (sixteen strains, read): sixteen independent row cells in flight per thread, the items of a chunk of
+        // strains on neighbouring threads (so that a level of 600 reads x 30 strains is three rounds of the workgroup, not
+        // two rounds of reads x four chunks one after the other).
+        constexpr int U = 16;
         const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-        for (int r = tid; r < Rn; r += nt) {
+        const int nch = (S + U - 1) / U;
+        const int items = Rn * nch;
+        for (int idx = tid; idx < items; idx += nt) {
+            const int ch = idx / Rn, r = idx - ch * Rn;
             const int e = e0 + r;
             const int rid = job.ent_rid[e];
             const int b = job.labels[job.ent_lab_off[e]];
-            const bool fresh = job.isnew[r] != 0;
-            for (int s0 = 0; s0 < S; s0 += U) {
-                double* cell[U];
-                double old[U];
+            const bool fresh = job.ent_first[e] && !job.has[rid];
+            if (ch == 0) job.isnew[r] = fresh ? 1 : 0;
+            const int s0 = ch * U;
+            long off[U];                                        // (no early exit from the unrolled loops: the arrays stay in registers)
+            double old[U];
 #pragma unroll
-                for (int k = 0; k < U; k++) {
-                    const int sx = (s0 + k < S) ? s0 + k : S - 1;
-                    cell[k] = job.ll + (long)s_sp[sx].slot * stride + rid;
-                    old[k] = fresh ? 0.0 : *cell[k];
-                }
+            for (int k = 0; k < U; k++) {
+                const int sx = (s0 + k < S) ? s0 + k : S - 1;
+                off[k] = (long)s_sp[sx].slot * stride + rid;
+                old[k] = fresh ? 0.0 : job.ll[off[k]];
+            }
 #pragma unroll
-                for (int k = 0; k < U; k++) {
-                    const int sx = s0 + k;
-                    if (sx >= S) break;
+            for (int k = 0; k < U; k++) {
+                const int sx = s0 + k;
+                if (sx < S) {
                     int a = s_lab[sx];
                     if (a == codeN) a = b;
                     const double val = (a < K && b < K) ? s_lpt[sx * K2 + a * K + b] : qnan;
-                    *cell[k] = fresh ? val : (old[k] + val);       // Strain::update_read_loglik, Strain.cpp:85-95
+                    job.ll[off[k]] = fresh ? val : (old[k] + val);       // Strain::update_read_loglik, Strain.cpp:85-95
                 }
             }
         }
@@ -673,7 +684,7 @@ __device__ __forceinline__ void phase_update(const JD& job, const LevelHdr& h, c
 }
 
 // phase 2: draw slots q = (entry, copy); the reference walks copies from cn down to 1 (:161-167)
-template <class JD>
+template <bool BARRIER = true, class JD>
 __device__ __forceinline__ void phase_slots(const JD& job, const LevelHdr& h, int tid, int nt) {
     const int e0 = h.e0, Rn = h.e1 - h.e0;
     for (int r = tid; r < Rn; r += nt) {
@@ -690,7 +701,7 @@ __device__ __forceinline__ void phase_slots(const JD& job, const LevelHdr& h, in
             job.qcode[qb + i] = code;
         }
     }
-    __syncthreads();
+    if (BARRIER) __syncthreads();
 }
 
 // every result of the level is in host memory before the stamp
@@ -799,9 +810,14 @@ __device__ __forceinline__ void level_sample_body(const IT& it, unsigned char* s
     }
     phase_copies(job, h, l.s_copy, tid, nt);
     if (tid == 0) R->phase_ticks[1] = (unsigned)(wall_clock64() - wall0);
-    if (upd) phase_update(job, h, l.s_sp, l.s_lab, reinterpret_cast<const double*>(l.s_big), tid, nt);
+    // the draw slots depend on the level's entries alone: their loads and stores go out in front of the update's, and
+    // the update's closing barriers cover them (phase_ticks[3] - [2] is therefore ~0 on a level with an update)
+    if (upd) {
+        phase_slots<false>(job, h, tid, nt);
+        phase_update(job, h, l.s_sp, l.s_lab, reinterpret_cast<const double*>(l.s_big), tid, nt);
+    }
     if (tid == 0) R->phase_ticks[2] = (unsigned)(wall_clock64() - wall0);
-    phase_slots(job, h, tid, nt);
+    if (!upd) phase_slots(job, h, tid, nt);
     if (tid == 0) R->phase_ticks[3] = (unsigned)(wall_clock64() - wall0);
 
     // what the sampler draws from.  Per draw slot q the fp32 weight row L[q][s] = exp(x_s - max_s x_s),
@@ -809,57 +825,66 @@ __device__ __forceinline__ void level_sample_body(const IT& it, unsigned char* s
     // <= 8 strains; the max is joined by shuffles.  A slot whose log-likelihoods lie in the underflow range of
     // the reference's exp() gets a NaN row, which sends its draws to the checked tiers.
     {
-        int G = 1;
-        while (G < 16 && G * 8 < S) G <<= 1;
-        const int per = (S + G - 1) / G;                     // <= 8 strains per lane
+        // A lane takes a draw slot q and walks the strains: the 64 slots of a wavefront are neighbouring reads (slots follow
+        // the level's entries, entries the read ids), so one load instruction -- one strain's row at 64 nearby read ids --
+        // touches a dozen cache lines instead of 64.  (A lane used to take eight strains of one slot: every 8-byte cell came
+        // with its own 128-byte line from the L2, 3.3 MB per level of 860 read copies x 30 strains at the 64 bytes a clock a
+        // compute unit gets -- 25 us, the longest part of a level outside the chain.)  Up to 32 strains the cells stay in
+        // registers between the maximum and the exponentials; beyond, they are read a second time (from the L1 / L2).
+        constexpr int SR = (NB <= 2) ? 16 * NB : 16;           // cells held per lane
         const long lstride = job.ll_stride;
         SC_GLOBAL float* rows_g = (SC_GLOBAL float*)job.tabLf;
-        auto put = [&](long idx, float v) __attribute__((always_inline)) { if (ROWS_LDS) s_rows[idx] = v; else rows_g[idx] = v; };
-        // one (slot, lane) item per thread and step; the read / mate ids of the NEXT item (two dependent loads) are
-        // fetched while this item's row cells (eight independent loads) and weights are worked on
-        const long QG = (long)Q * G;
-        int rid_n = 0, uid_n = -1;
-        auto fetch = [&](long g_) __attribute__((always_inline)) { const long q_ = g_ / G; rid_n = job.ent_rid[e0 + job.qent[q_]]; uid_n = job.quid[q_]; };
-        if (tid < QG) fetch(tid);
-        {
-            for (long gid = tid; gid < QG; gid += nt) {          // lanes of one slot are adjacent and leave together
-                const int rid_c = rid_n, uid_c = uid_n;
-                if (gid + nt < QG) fetch(gid + nt);
-                const bool hr_c = h.do_update ? true : job.has[rid_c] != 0;      // the update has just entered the level's reads
-                const bool hu_c = uid_c >= 0 && job.has[uid_c] != 0;
-                const int g = (int)(gid % G);
-                const long q = gid / G;
-                const int s0 = g * per, s1 = (s0 + per < S) ? s0 + per : S;
-                double x[8], m = -INFINITY;
+        auto put4 = [&](long idx, f4v v) __attribute__((always_inline)) {
+            if (ROWS_LDS) *(f4v*)(s_rows + idx) = v; else *(SC_GLOBAL f4v*)(rows_g + idx) = v;
+        };
+        const float qnanf = __int_as_float(0x7fc00000);
+        for (int q = tid; q < Q; q += nt) {
+            const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
+            const bool hr = h.do_update ? true : job.has[rid] != 0;      // the update has just entered the level's reads
+            const bool hu = uid >= 0 && job.has[uid] != 0;
+            const int c0 = job.qcode[q];
+            const float symf = __int_as_float(c0 < KMAX ? c0 : KMAX);    // the read symbol rides behind the weights (a tiny denormal under a zero count: no effect on the sums)
+            const long Lf = (long)q * stride;
+            auto cell = [&](int sx) __attribute__((always_inline)) -> double {
+                const double* row = job.ll + (long)l.s_slot[sx] * lstride;
+                double v = hr ? row[rid] : 0.0;
+                if (hu) v += row[uid];
+                return v;
+            };
+            double m = -INFINITY;
+            double x[SR];
+            if (NB <= 2) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int sx = s0 + i;
-                    x[i] = -INFINITY;
-                    if (sx < s1) {
-                        const double* row = job.ll + (long)l.s_slot[sx] * lstride;
-                        double v = hr_c ? row[rid_c] : 0.0;
-                        if (hu_c) v += row[uid_c];
-                        x[i] = v;
-                        m = fmax(m, v);
-                    }
-                }
-                for (int d = 1; d < G; d <<= 1) m = fmax(m, __shfl_xor(m, d));       // G is a power of two <= 16: lanes of one slot are adjacent
-                const bool flag = !(m >= -600.0);                // underflow range of the reference's exp(); also NaN / -inf
-                const long Lf = q * stride;
+                for (int i = 0; i < SR; i++) { x[i] = -INFINITY; if (i < S) { x[i] = cell(i); m = fmax(m, x[i]); } }
+            } else {
+                for (int s0 = 0; s0 < S; s0 += SR) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int sx = s0 + i;
-                    if (sx < s1) put(Lf + sx, flag ? __int_as_float(0x7fc00000) : exp_weight(x[i] - m));
-                }
-                if (g == 0) {
-                    // the read symbol rides behind the weights (a tiny denormal under a zero count: no effect on the sums)
-                    const int c0 = job.qcode[q];
-                    put(Lf + S, __int_as_float(c0 < KMAX ? c0 : KMAX));
-                    for (int sx = S + 1; sx < stride; sx++) put(Lf + sx, 0.0f);
-                    // the chain reads whole 16-strain blocks: keep what follows the last row finite
-                    if (q == Q - 1) for (int i = 0; i < 16; i++) put(Lf + stride + i, 0.0f);
+                    for (int i = 0; i < SR; i++) if (s0 + i < S) m = fmax(m, cell(s0 + i));
                 }
             }
+            const bool flag = !(m >= -600.0);                // underflow range of the reference's exp(); also NaN / -inf
+            // the row: S weights, the symbol, zeros up to the stride (a multiple of four floats)
+            for (int s0 = 0; s0 < stride; s0 += SR) {
+                if (NB > 2) {
+#pragma unroll
+                    for (int i = 0; i < SR; i++) x[i] = (s0 + i < S) ? cell(s0 + i) : -INFINITY;
+                }
+#pragma unroll
+                for (int i = 0; i < SR; i += 4) {
+                    if (s0 + i < stride) {
+                        f4v w;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int sx = s0 + i + k;
+                            const float wk = sx < S ? (flag ? qnanf : exp_weight(x[i + k] - m)) : (sx == S ? symf : 0.0f);
+                            if (k == 0) w.x = wk; else if (k == 1) w.y = wk; else if (k == 2) w.z = wk; else w.w = wk;
+                        }
+                        put4(Lf + s0 + i, w);
+                    }
+                }
+            }
+            // the chain reads whole 16-strain blocks: keep what follows the last row finite
+            if (q == Q - 1) for (int i = 0; i < 16; i += 4) put4(Lf + stride + i, f4v{0.0f, 0.0f, 0.0f, 0.0f});
         }
     }
     __syncthreads();
