@@ -270,6 +270,15 @@ template <int QP> __device__ __forceinline__ int quad_i32(int v) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int UWIN = 1024;     // uniforms staged in LDS (fp32), refilled in halves
+#ifdef SC_CHAIN_PROF
+// experiment builds only (make EXTRA=-DSC_CHAIN_PROF): where a pass of the chain spends its cycles, summed over every pass
+// of wave 0: [0] counts read + chains, [1] test + s_x write, [2] first barrier + advance, [3] commits, [4] second barrier,
+// [5] passes
+__device__ unsigned long long g_chain_prof[12];
+#define CHAIN_STAMP(k) do { if (wv == 0) { const unsigned long long t_ = clock64(); prof[k] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define CHAIN_STAMP(k) do {} while (0)
+#endif
 
 template <int NQ, bool ROWS_LDS, int NW, class JD>
 __device__ __forceinline__ void urn_chain_q(const JD& job, const LevelHdr& h, const StrainParam* s_sp, LevelResult* __restrict__ R,
@@ -278,7 +287,9 @@ __device__ __forceinline__ void urn_chain_q(const JD& job, const LevelHdr& h, co
     constexpr int SPL = 4 * NQ, SP = 16 * NQ;               // strains per lane, capacity
     constexpr int NPLC = SP > 64 ? 2 : 1;                  // strains per lane in the checked tier
     constexpr float EPSW = (float)(SP + 16) * 1.5e-7f;     // (2*S + 9) * 2^-24 for the chains and sums + 3 * 2^-24 for the weights (exp_weight)
-    const int lane = tid & 63, wv = tid >> 6, k = lane & 3, pos = wv * 16 + (lane >> 2);
+    // (the wavefront's index as a scalar: what only wavefront 0 does -- the uniforms, the checked tiers -- then costs the
+    // others a scalar branch instead of a walk through masked-off vector code)
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), k = lane & 3, pos = wv * 16 + (lane >> 2);
     const int S = h.S, Q = h.Q, n = h.n_sweeps, e0 = h.e0;
     const int Sm1 = S - 1;
     const int total = n * Q;
@@ -328,6 +339,9 @@ __device__ __forceinline__ void urn_chain_q(const JD& job, const LevelHdr& h, co
         uf = s_uwin[upos];
     };
     if (total > 0) issue_loads();
+#ifdef SC_CHAIN_PROF
+    unsigned long long prof[5] = {0, 0, 0, 0, 0}, tprev = clock64();
+#endif
 #pragma unroll 1
     while (t < total) {
         asm volatile("" ::: "memory");                      // s_kf below must be re-read
@@ -335,16 +349,22 @@ __device__ __forceinline__ void urn_chain_q(const JD& job, const LevelHdr& h, co
         // this lane's quarter: cumulative weights with the counts in front of draw t
         float loc[SPL];
         float run = 0.0f;
+        u4v kq[NQ];
+#pragma unroll
+        for (int g = 0; g < NQ; g++) kq[g] = *(const u4v*)(s_kf + cbase + 4 * g);
+        const unsigned klast = s_kf[Sm1];                       // (read with the others: one LDS round trip, not two)
+        const float a0last = s_a0f[Sm1];
 #pragma unroll
         for (int g = 0; g < NQ; g++) {
-            const u4v kk = *(const u4v*)(s_kf + cbase + 4 * g);
+            const u4v kk = kq[g];
             const f4v av = a0q[g] + f4v{(float)kk.x, (float)kk.y, (float)kk.z, (float)kk.w};
             loc[4 * g + 0] = run = (g == 0) ? av.x * L[g].x : fma_rn(av.x, L[g].x, run);
             loc[4 * g + 1] = run = fma_rn(av.y, L[g].y, run);
             loc[4 * g + 2] = run = fma_rn(av.z, L[g].z, run);
             loc[4 * g + 3] = run = fma_rn(av.w, L[g].w, run);
         }
-        const float alast = s_a0f[Sm1] + (float)s_kf[Sm1];
+        const float alast = a0last + (float)klast;
+        CHAIN_STAMP(0);
         // quad: offset of this quarter and the total weight (bitwise the same in the four lanes)
         const float i1 = fmaf(quad_f32<0x90>(run), m0, run);       // + previous lane of the quad   ([0,0,1,2])
         const float i2 = fmaf(quad_f32<0x40>(i1), m1, i1);         // + two lanes back              ([0,0,0,1])
@@ -384,6 +404,7 @@ __device__ __forceinline__ void urn_chain_q(const JD& job, const LevelHdr& h, co
         c += quad_i32<0xB1>(c);
         c += quad_i32<0x4E>(c);
         c = min(c, Sm1);
+        CHAIN_STAMP(1);
         lds_barrier();
         const int rem = total - t;
         int adv = 16 * NW;
@@ -393,6 +414,7 @@ __device__ __forceinline__ void urn_chain_q(const JD& job, const LevelHdr& h, co
             adv = min(adv, min(min(xf.x, xf.y), min(xf.z, xf.w)));
         }
         adv = adv < rem ? adv : rem;
+        CHAIN_STAMP(2);
         if (adv == 0) {
             // draw t itself: fp64 scan with the exact counts, then the literal tier (wave 0)
             if (wv == 0) {
@@ -442,8 +464,13 @@ __device__ __forceinline__ void urn_chain_q(const JD& job, const LevelHdr& h, co
         issue_loads();                                       // rows of the new window first, then the commit
         if (acc) __hip_atomic_fetch_add(&s_kf[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (accs) __hip_atomic_fetch_add(&s_cnt[cs], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        CHAIN_STAMP(3);
         lds_barrier();                                       // every wave's commits are in s_kf
+        CHAIN_STAMP(4);
     }
+#ifdef SC_CHAIN_PROF
+    if (tid == 0) { for (int i = 0; i < 5; i++) atomicAdd(&g_chain_prof[i], prof[i]); atomicAdd(&g_chain_prof[5], n_pass); }
+#endif
     __syncthreads();
     if (wv == 0) {
 #pragma unroll
@@ -1603,3 +1630,8 @@ void launch_thread(hipStream_t st, const ThreadDev& d, int* pool_sorted) {
 }
 
 }  // namespace sc
+#ifdef SC_CHAIN_PROF
+extern "C" int sc_debug_chain_prof(unsigned long long* out) {       // experiment builds only
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sc::g_chain_prof), sizeof(unsigned long long) * 12);
+}
+#endif
