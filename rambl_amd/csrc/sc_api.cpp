@@ -839,6 +839,12 @@ int Worker::msa_device(const std::vector<std::string>& seqs, std::vector<std::st
 void Worker::thread_device(const std::string& G, const std::vector<AlignedRead>& R, const std::vector<std::vector<CigarOp>>& cig,
                            ThreadTables& T) {
     const int glen = (int)G.size(), n = (int)R.size();
+#ifdef SC_GRAPH_TIMING
+    double tdp_ = now_ms();
+#define SC_DPHASE(name) do { HIPCHK(hipStreamSynchronize(st)); const double t_ = now_ms(); fprintf(stderr, "      thread_device %-12s %.2f ms\n", name, t_ - tdp_); tdp_ = t_; } while (0)
+#else
+#define SC_DPHASE(name) do {} while (0)
+#endif
     // symbol table of the READS: A C G T first, then every other byte that occurs in a read, in byte order.  A base of the
     // gene that no read carries (an IUPAC code of a 16S reference) keeps the code 0xFF: no read base equals it, so every
     // read base aligned there lands in a sibling class, as `G[i]==r[j]` decides in the reference (PartialOrderGraph.cpp:133)
@@ -861,6 +867,7 @@ void Worker::thread_device(const std::string& G, const std::vector<AlignedRead>&
         for (const CigarOp& c : cig[r]) { cig_op.push_back(c.op); cig_len.push_back(c.len); if (c.op == 'M') m_bases += c.len; }
         cig_off[r + 1] = (int)cig_op.size();
     }
+    SC_DPHASE("pack");
     const int ncls = glen * 8;
     ThreadDev d{};
     d.glen = glen; d.n_reads = n;
@@ -880,17 +887,19 @@ void Worker::thread_device(const std::string& G, const std::vector<AlignedRead>&
     uint8_t* dlut = (uint8_t*)t_lut.ensure(256);
     stage->h2d(dlut, T.lut, 256, st);
     d.lut = dlut;
-    // tables: count | minrid | smin | emin (ncls each) | tmin (8*ncls) | off (ncls+1) | cursor (ncls) | err
-    const size_t words = (size_t)ncls * 4 + (size_t)ncls * 8 + (size_t)ncls + 1 + (size_t)ncls + 1;
+    // tables: count | minrid | smin | emin (ncls each) | tmin (8*ncls) | off (ncls+1) | cursor (ncls) | err | big (1 + ncls)
+    const size_t words = (size_t)ncls * 4 + (size_t)ncls * 8 + (size_t)ncls + 1 + (size_t)ncls + 1 + 1 + (size_t)ncls;
     int* tabs = (int*)t_tabs.ensure(sizeof(int) * words);
     d.count = tabs; d.minrid = tabs + ncls; d.smin = tabs + 2 * (size_t)ncls; d.emin = tabs + 3 * (size_t)ncls;
-    d.tmin = tabs + 4 * (size_t)ncls; d.off = tabs + 12 * (size_t)ncls; d.cursor = d.off + ncls + 1; d.err = d.cursor + ncls;
+    d.tmin = tabs + 4 * (size_t)ncls; d.off = tabs + 12 * (size_t)ncls; d.cursor = d.off + ncls + 1; d.err = d.cursor + ncls; d.big = d.err + 1;
     HIPCHK(hipMemsetAsync(d.count, 0, sizeof(int) * (size_t)ncls, st));
     HIPCHK(hipMemsetAsync(d.minrid, 0x7f, sizeof(int) * (size_t)ncls * 11, st));          // minrid, smin, emin, tmin = 0x7f7f7f7f
-    HIPCHK(hipMemsetAsync(d.off, 0, sizeof(int) * ((size_t)ncls * 2 + 2), st));           // off, cursor, err
+    HIPCHK(hipMemsetAsync(d.off, 0, sizeof(int) * ((size_t)ncls * 2 + 3), st));           // off, cursor, err, the count of big classes
     d.pool = (int*)t_pool.ensure(sizeof(int) * (size_t)std::max<long>(m_bases, 1));
     int* pool_sorted = (int*)t_pool2.ensure(sizeof(int) * (size_t)std::max<long>(m_bases, 1));
+    SC_DPHASE("uploads");
     launch_thread(st, d, pool_sorted);
+    SC_DPHASE("kernels");
     T.count.resize(ncls); T.minrid.resize(ncls); T.smin.resize(ncls); T.emin.resize(ncls);
     T.tmin.resize((size_t)ncls * 8); T.off.resize((size_t)ncls + 1); T.pool.resize((size_t)m_bases);
     int err = 0;
@@ -906,6 +915,8 @@ void Worker::thread_device(const std::string& G, const std::vector<AlignedRead>&
     sync_stream();
     stage->land();
     if (getenv("SC_SYNC_LOG")) fprintf(stderr, "sync thread_device %.3f ms\n", now_ms() - t_sync0);
+    SC_DPHASE("downloads");
+#undef SC_DPHASE
     if (err) throw ScError(SC_ERR_ARG, "a read runs outside the window or past its own bases");
     const int INF = 0x7fffffff;
     auto fix = [&](std::vector<int>& v) { for (int& x : v) if (x == 0x7f7f7f7f) x = INF; };
@@ -982,7 +993,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         int qo = 0;
         for (int i = 0; i < n_reads; i++) {
             f.ent_rid.push_back(i); f.ent_cn.push_back(job.reads[i].cn); f.ent_lab_off.push_back(0);
-            f.ent_lab_len.push_back(0); f.ent_first.push_back(1); f.ent_node.push_back(-1);
+            f.ent_lab_len.push_back(0); f.ent_first.push_back(1);
             qo += job.reads[i].cn;
         }
         total_copies = qo;
@@ -1626,6 +1637,9 @@ void Worker::process(Job& job) {
             job.thr_count = T.count; job.thr_first = T.minrid; job.thr_pool = T.pool; job.thr_sym.assign(T.sym.begin(), T.sym.end());
         }
     };
+    // a context with one region in flight gives the region's bulk copies (class pools, flattening: 88 M entries on the
+    // unthinned configs[3] region) the rank's other CPUs; with many in flight those already run other regions
+    sc::set_graph_threads(ctx->workers.size() == 1 ? std::min(8, std::max(1, (int)(sc::cpu_budget_host() / sc::local_world_size()))) : 1);
     PoGraph g(job.ref, job.reads, msa, thr);
     job.stats.msa_calls = g.msa_calls;
     if (job.params.graph_only || job.params.want_graph) job.graph_dump = g.dump();      // -G text, PartialOrderGraph.cpp:318-337

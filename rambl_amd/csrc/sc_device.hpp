@@ -154,6 +154,7 @@ struct ThreadDev {
     int* off; int* cursor;      // [glen*8 + 1]
     int* pool;                  // [total M bases]
     int* err;                   // nonzero: a read runs outside the window / its bases
+    int* big;                   // [1 + glen*8] classes whose pool spans too many read ids for a wavefront's bitmap: count, then the list
 };
 
 // Buffers of one progressive MSA call (k_msa).

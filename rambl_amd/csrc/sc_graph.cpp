@@ -8,8 +8,27 @@
 #include <algorithm>
 #include <cstring>
 #include <stdexcept>
+#include <atomic>
+#include <thread>
 
 namespace sc {
+
+static thread_local int tl_graph_threads = 1;
+void set_graph_threads(int n) { tl_graph_threads = n < 1 ? 1 : (n > 64 ? 64 : n); }
+int graph_threads() { return tl_graph_threads; }
+// fn(i) for i in [0, n), on up to `threads` threads taking indices from a shared counter (the items differ in size by
+// orders of magnitude: a backbone class of 59 000 reads beside a sibling of three); exceptions of a helper end the process
+// as they would on the calling thread
+template <class F>
+static void parallel_items(int n, int threads, const F& fn) {
+    if (threads <= 1 || n < 2) { for (int i = 0; i < n; i++) fn(i); return; }
+    std::atomic<int> next{0};
+    auto body = [&] { for (int i = next.fetch_add(1, std::memory_order_relaxed); i < n; i = next.fetch_add(1, std::memory_order_relaxed)) fn(i); };
+    std::vector<std::thread> ts;
+    for (int t = 1; t < threads; t++) ts.emplace_back(body);
+    body();
+    for (auto& t : ts) t.join();
+}
 
 // ---------------------------------------------------------------------------
 // std::sort as libstdc++ permutes it (GCC <bits/stl_algo.h>: introsort with
@@ -590,6 +609,13 @@ void PoGraph::finalize_ids() {
 void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>& R, const ThreadFn& thread) {
     const int glen = (int)G.size();
     const int n = (int)R.size();
+#ifdef SC_GRAPH_TIMING
+    auto tnow_ = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double ttp_ = tnow_();
+#define SC_TPHASE(name) do { const double t_ = tnow_(); fprintf(stderr, "    thread_reads %-14s %.2f ms\n", name, t_ - ttp_); ttp_ = t_; } while (0)
+#else
+#define SC_TPHASE(name) do {} while (0)
+#endif
     std::vector<std::vector<CigarOp>> cig(n);
     std::vector<char> complex_read(n, 0);
     for (int r = 0; r < n; r++) {
@@ -599,8 +625,10 @@ void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>&
             else if (c.op != 'M') throw std::runtime_error("CIGAR operation other than M/I/D/=/X in a cropped read");
         }
     }
+    SC_TPHASE("cigars");
     ThreadTables T;
     thread(G, R, cig, T);
+    SC_TPHASE("thread stage");
     const int INF = 0x7fffffff;
     if ((int)T.sym.size() > 8) throw std::runtime_error("more than 8 distinct symbols in the reads");
 
@@ -726,6 +754,7 @@ void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>&
             (void)u_is_end;
         }
     }
+    SC_TPHASE("events");
     auto ev_less = [](const Event& a, const Event& b) {
         if (a.rid != b.rid) return a.rid < b.rid;
         if (a.op != b.op) return a.op < b.op;
@@ -740,6 +769,7 @@ void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>&
     } else {
         std::stable_sort(ev.begin(), ev.end(), ev_less);
     }
+    SC_TPHASE("event sort");
     // replay
     std::vector<int> class_node((size_t)glen * 8, -1);
     for (int i = 0; i < glen; i++) if (ref_code(i) < 8) class_node[(size_t)i * 8 + ref_code(i)] = i + 1;   // a gene base no read carries has no class
@@ -769,23 +799,28 @@ void PoGraph::thread_reads(const std::string& G, const std::vector<AlignedRead>&
             if (e.force || (!linking(a, b) && !(e.check_ne && a == b))) add_edge(a, b);
         }
     }
+    SC_TPHASE("replay");
     // pools of the backbone / sibling nodes, in read order (a million entries: copy numbers from a compact array, written by index)
     std::vector<int> copies((size_t)n);
     for (int r = 0; r < n; r++) copies[(size_t)r] = R[r].cn;
-    for (int i = 0; i < glen; i++)
-        for (int c = 0; c < 8; c++) {
-            const int cls = i * 8 + c;
-            if (T.count[cls] == 0) continue;
-            const int w = class_node[cls];
-            if (w < 0) throw std::runtime_error("class without a node");
-            auto& pool = nodes[w].pool;
-            const int lab = intern(std::string(1, T.sym[c]));
-            const size_t at = pool.size(), cnt = (size_t)(T.off[cls + 1] - T.off[cls]);
-            pool.resize(at + cnt);
-            PoolEnt* dst = pool.data() + at;
-            const int* src = T.pool.data() + T.off[cls];
-            for (size_t x = 0; x < cnt; x++) dst[x] = PoolEnt{src[x], copies[(size_t)src[x]], lab};
-        }
+    int sym_lab[8];
+    for (int c = 0; c < 8; c++) sym_lab[c] = c < (int)T.sym.size() ? intern(std::string(1, T.sym[c])) : -1;
+    for (int cls = 0; cls < glen * 8; cls++)
+        if (T.count[cls] != 0 && class_node[cls] < 0) throw std::runtime_error("class without a node");
+    // a class has a node of its own: the pools fill independently of each other (on a deep region this is 88 M entries)
+    const int fill_threads = (long)T.pool.size() > (1L << 22) ? graph_threads() : 1;
+    parallel_items(glen * 8, fill_threads, [&](int cls) {
+        if (T.count[cls] == 0) return;
+        auto& pool = nodes[class_node[cls]].pool;
+        const int lab = sym_lab[cls & 7];
+        const size_t at = pool.size(), cnt = (size_t)(T.off[cls + 1] - T.off[cls]);
+        pool.resize(at + cnt);
+        PoolEnt* dst = pool.data() + at;
+        const int* src = T.pool.data() + T.off[cls];
+        for (size_t x = 0; x < cnt; x++) dst[x] = PoolEnt{src[x], copies[(size_t)src[x]], lab};
+    });
+    SC_TPHASE("pools");
+#undef SC_TPHASE
 }
 
 // cpp:67-265
@@ -903,33 +938,133 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
         f.out_ptr[a + 1] = f.out_ptr[a] + (int)x.out.size();
         for (int o : x.out) f.out_node.push_back(g.nodes[o].id);
         f.pool_ptr[a + 1] = f.pool_ptr[a] + (int)x.pool.size();
-        int prev = -1;
-        int* pr = f.pool_rid.data() + f.pool_ptr[a]; int* pc = f.pool_cn.data() + f.pool_ptr[a];
-        size_t k = 0;
-        for (const auto& e : x.pool) {
-            pr[k] = e.rid; pc[k] = e.cn; k++;
-            if (e.rid < prev) f.pools_sorted = false;
-            prev = e.rid;
-        }
+    }
+    const int bulk_threads = (long)n_pool > (1L << 22) ? graph_threads() : 1;
+    {
+        std::atomic<bool> sorted{true};
+        parallel_items(f.n_nodes, bulk_threads, [&](int a) {
+            const GNode& x = g.nodes[alive[a]];
+            int prev = -1;
+            int* pr = f.pool_rid.data() + f.pool_ptr[a]; int* pc = f.pool_cn.data() + f.pool_ptr[a];
+            size_t k = 0;
+            bool ok = true;
+            for (const auto& e : x.pool) {
+                pr[k] = e.rid; pc[k] = e.cn; k++;
+                if (e.rid < prev) ok = false;
+                prev = e.rid;
+            }
+            if (!ok) sorted.store(false, std::memory_order_relaxed);
+        });
+        if (!sorted.load()) f.pools_sorted = false;
     }
     f.out_support.assign(f.out_node.size(), 0);
     SC_PHASE("nodes + pools");
 
     // level walk, NonparametricClustering.cpp:284-334 and :556-575.  A million entries per region: the arrays grow a node's
     // pool at a time and are written by index (this loop was more than half of a region's set-up on the host).
-    std::vector<int> level_node{0}, sub;
-    std::vector<int> visited(f.n_nodes, -1);
-    int level = 0;
-    f.level_node_ptr.push_back(0);
-    f.level_ent_ptr.push_back(0);
-    std::vector<int> rid_stamp((size_t)std::max(n_reads, 1), -1);
     std::vector<int> lab_off(g.labtab.size(), -1), lab_len(g.labtab.size(), 0);
     for (size_t i = 0; i < g.labtab.size(); i++) lab_len[i] = (int)g.labtab[i].size();
     size_t ne = 0;                                              // entries so far
+    int level = 0;
+    if (bulk_threads > 1) {
+        // A deep region (88 M entries): the same walk in three passes.  (1) the order of the walk alone -- the nodes of every
+        // level, where each one's entries go; (2) in parallel over the walk's nodes, the labels each pool carries, in the order
+        // it first carries them, merged in walk order into the coding a single pass would have produced (symbol codes are handed
+        // out in the order the entries are walked); (3) in parallel over the LEVELS (the first occurrence of a read is a matter
+        // of one level), the entries themselves.
+        std::vector<int> level_node{0}, sub;
+        std::vector<int> visited(f.n_nodes, -1);
+        std::vector<size_t> item_off;                           // per walked node: where its entries start (SIZE_MAX: none)
+        f.level_node_ptr.push_back(0);
+        f.level_ent_ptr.push_back(0);
+        while (!level_node.empty()) {
+            int end_pos = -1;
+            for (size_t qi = 0; qi < level_node.size(); qi++) {
+                const int a = level_node[qi];
+                const GNode& x = g.nodes[alive[a]];
+                f.level_nodes.push_back(a);
+                if (a == 0) item_off.push_back(SIZE_MAX);
+                else if (f.node_is_end[a]) { end_pos = (int)qi; item_off.push_back(SIZE_MAX); }
+                else { item_off.push_back(ne); ne += x.pool.size(); }
+                for (int o : x.out) {
+                    const int b = g.nodes[o].id;
+                    if (visited[b] != level) { sub.push_back(b); visited[b] = level; }
+                }
+            }
+            f.level_node_ptr.push_back((int)f.level_nodes.size());
+            f.level_ent_ptr.push_back((int)ne);
+            f.level_has_end.push_back(end_pos >= 0);
+            f.level_end_pos.push_back(end_pos);
+            level += 1;
+            level_node.swap(sub);
+            sub.clear();
+        }
+        const int n_items = (int)f.level_nodes.size();
+        std::vector<std::vector<int>> firsts((size_t)n_items);
+        {
+            std::atomic<int> next{0};
+            auto scan = [&] {
+                std::vector<int> seen(g.labtab.size(), -1);
+                for (int it = next.fetch_add(1); it < n_items; it = next.fetch_add(1)) {
+                    if (item_off[(size_t)it] == SIZE_MAX) continue;
+                    for (const auto& e : g.nodes[alive[f.level_nodes[(size_t)it]]].pool)
+                        if (seen[(size_t)e.lab] != it) { seen[(size_t)e.lab] = it; firsts[(size_t)it].push_back(e.lab); }
+                }
+            };
+            std::vector<std::thread> ts;
+            for (int t = 1; t < bulk_threads; t++) ts.emplace_back(scan);
+            scan();
+            for (auto& t : ts) t.join();
+        }
+        for (int it = 0; it < n_items; it++)
+            for (int lab : firsts[(size_t)it])
+                if (lab_off[(size_t)lab] < 0) {
+                    lab_off[(size_t)lab] = (int)f.labels.size();
+                    for (char c : g.labtab[(size_t)lab]) f.labels.push_back(code(c));
+                }
+        f.ent_rid.resize(ne); f.ent_cn.resize(ne); f.ent_lab_off.resize(ne); f.ent_lab_len.resize(ne); f.ent_first.resize(ne);
+        f.level_read_count.assign((size_t)level, 0);
+        {
+            std::atomic<int> next{0};
+            auto fill = [&] {
+                std::vector<int> rid_stamp((size_t)std::max(n_reads, 1), -1);
+                for (int lv = next.fetch_add(1); lv < level; lv = next.fetch_add(1)) {
+                    int lrc = 0;
+                    for (int it = f.level_node_ptr[(size_t)lv]; it < f.level_node_ptr[(size_t)lv + 1]; it++) {
+                        if (item_off[(size_t)it] == SIZE_MAX) continue;
+                        const GNode& x = g.nodes[alive[f.level_nodes[(size_t)it]]];
+                        const size_t at = item_off[(size_t)it];
+                        int* er = f.ent_rid.data() + at; int* ec = f.ent_cn.data() + at;
+                        int* eo = f.ent_lab_off.data() + at; int* el = f.ent_lab_len.data() + at; uint8_t* ef = f.ent_first.data() + at;
+                        size_t k = 0;
+                        for (const auto& e : x.pool) {
+                            er[k] = e.rid; ec[k] = e.cn;
+                            eo[k] = lab_off[(size_t)e.lab]; el[k] = lab_len[(size_t)e.lab];
+                            if ((size_t)e.rid >= rid_stamp.size()) rid_stamp.resize((size_t)e.rid + 1, -1);
+                            ef[k] = rid_stamp[(size_t)e.rid] != lv;
+                            rid_stamp[(size_t)e.rid] = lv;
+                            lrc += e.cn;
+                            k++;
+                        }
+                    }
+                    f.level_read_count[(size_t)lv] = lrc;
+                }
+            };
+            std::vector<std::thread> ts;
+            for (int t = 1; t < bulk_threads; t++) ts.emplace_back(fill);
+            fill();
+            for (auto& t : ts) t.join();
+        }
+    } else {
+    std::vector<int> level_node{0}, sub;
+    std::vector<int> visited(f.n_nodes, -1);
+    f.level_node_ptr.push_back(0);
+    f.level_ent_ptr.push_back(0);
+    std::vector<int> rid_stamp((size_t)std::max(n_reads, 1), -1);
     auto grow = [&](size_t n) {
         if (n <= f.ent_rid.size()) return;
         const size_t cap = std::max(n, f.ent_rid.size() + f.ent_rid.size() / 2 + 1024);
-        f.ent_rid.resize(cap); f.ent_cn.resize(cap); f.ent_node.resize(cap); f.ent_lab_off.resize(cap); f.ent_lab_len.resize(cap);
+        f.ent_rid.resize(cap); f.ent_cn.resize(cap); f.ent_lab_off.resize(cap); f.ent_lab_len.resize(cap);
         f.ent_first.resize(cap);
     };
     grow(n_pool + 16);
@@ -944,11 +1079,11 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
                 end_pos = (int)qi;
             } else {
                 grow(ne + x.pool.size());
-                int* er = f.ent_rid.data() + ne; int* ec = f.ent_cn.data() + ne; int* en = f.ent_node.data() + ne;
+                int* er = f.ent_rid.data() + ne; int* ec = f.ent_cn.data() + ne;
                 int* eo = f.ent_lab_off.data() + ne; int* el = f.ent_lab_len.data() + ne; uint8_t* ef = f.ent_first.data() + ne;
                 size_t k = 0;
                 for (const auto& e : x.pool) {
-                    er[k] = e.rid; ec[k] = e.cn; en[k] = a;
+                    er[k] = e.rid; ec[k] = e.cn;
                     // a label is coded where an entry first carries it (symbol codes are handed out in the order the
                     // entries are walked) and shared by every later entry
                     int lo = lab_off[(size_t)e.lab];
@@ -981,7 +1116,8 @@ void flatten(const PoGraph& g, int n_reads, FlatGraph& f) {
         level_node.swap(sub);
         sub.clear();
     }
-    f.ent_rid.resize(ne); f.ent_cn.resize(ne); f.ent_node.resize(ne); f.ent_lab_off.resize(ne); f.ent_lab_len.resize(ne); f.ent_first.resize(ne);
+    }
+    f.ent_rid.resize(ne); f.ent_cn.resize(ne); f.ent_lab_off.resize(ne); f.ent_lab_len.resize(ne); f.ent_first.resize(ne);
     SC_PHASE("level walk");
 #undef SC_PHASE
     f.n_levels = level;

@@ -126,6 +126,12 @@ void std_sort_perm(std::vector<int>& idx, const std::function<bool(int, int)>& l
 
 // ---------------------------------------------------------------------------
 // Level-major flattening for the device.
+// Host threads the construction of ONE region's graph may use for its bulk copies (class pools, flattening): 1 while many
+// regions are in flight (they already fill the rank's CPUs), more for a single deep region (BASELINE configs[3]: 88 M pool
+// entries).  Thread-local: set by the worker that builds the graph.
+void set_graph_threads(int n);
+int graph_threads();
+
 struct FlatGraph {
     // symbol table: code 0..5 = A C G T - = ; further codes in order of appearance
     std::vector<char> sym;            // code -> char
@@ -144,7 +150,7 @@ struct FlatGraph {
     int n_levels = 0;
     std::vector<int> level_node_ptr, level_nodes;  // nodes popped at each level, in order
     std::vector<int> level_ent_ptr;                // entries (level_reads) per level
-    std::vector<int> ent_rid, ent_cn, ent_lab_off, ent_lab_len, ent_node;
+    std::vector<int> ent_rid, ent_cn, ent_lab_off, ent_lab_len;
     std::vector<uint8_t> ent_first;                // first occurrence of rid within its level
     std::vector<int> level_read_count;
     std::vector<uint8_t> level_has_end;            // "$" popped in this level
@@ -161,7 +167,7 @@ struct FlatGraph {
         node_lab_off.clear(); node_lab_len.clear(); labels.clear(); node_label_str.clear(); node_is_end.clear();
         out_ptr.clear(); out_node.clear(); out_support.clear();
         n_levels = 0; level_node_ptr.clear(); level_nodes.clear(); level_ent_ptr.clear();
-        ent_rid.clear(); ent_cn.clear(); ent_lab_off.clear(); ent_lab_len.clear(); ent_node.clear(); ent_first.clear();
+        ent_rid.clear(); ent_cn.clear(); ent_lab_off.clear(); ent_lab_len.clear(); ent_first.clear();
         level_read_count.clear(); level_has_end.clear(); level_end_pos.clear();
         pool_ptr.clear(); pool_rid.clear(); pool_cn.clear();
         pools_sorted = true; unsupported.clear();

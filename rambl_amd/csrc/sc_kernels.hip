@@ -1430,9 +1430,14 @@ __global__ __launch_bounds__(1024) void k_thread_scan(const int* __restrict__ co
 
 // every pool into ascending read order (ids are distinct inside a class).  Reads are sorted by
 // start position, so the reads of one class span a short id range: a bitmap of that range in LDS
-// gives every read its rank with two popcounts; wider ranges fall back to a quadratic rank sort.
-__global__ __launch_bounds__(256) void k_thread_sort(const int* __restrict__ off, const int* __restrict__ in, int* __restrict__ out, int ncls) {
-    constexpr int WORDS = 256;                       // 8192 ids per wavefront
+// gives every read its rank with two popcounts.  A class whose reads span more ids than a wavefront's
+// bitmap holds (deep coverage: 59 000 reads over every position of configs[3]) goes on the list of
+// k_thread_sort_big, which gives it a whole workgroup and a bitmap of half a million ids.  (Until round 3 such a class was
+// ranked by comparing every read with every other: 9.3 s of the 19 s of the unthinned configs[3] region.)
+constexpr int SORT_WORDS = 512;
+__global__ __launch_bounds__(256) void k_thread_sort(const int* __restrict__ off, const int* __restrict__ in, int* __restrict__ out, int ncls,
+                                                     int* __restrict__ big) {
+    constexpr int WORDS = SORT_WORDS;                // 16 384 ids per wavefront
     __shared__ unsigned bits[4][WORDS];
     __shared__ int wpre[4][WORDS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1451,7 +1456,7 @@ __global__ __launch_bounds__(256) void k_thread_sort(const int* __restrict__ off
             __builtin_amdgcn_wave_barrier();
             for (int x = lane; x < n; x += 64) { const int v = in[b + x] - lo; atomicOr(&bits[w][v >> 5], 1u << (v & 31)); }
             __builtin_amdgcn_wave_barrier();
-            // exclusive prefix of the word popcounts (nw <= 256: four words per lane)
+            // exclusive prefix of the word popcounts (nw <= 512: eight words per lane)
             int run = 0;
             for (int k0 = 0; k0 < nw; k0 += 64) {
                 const int k = k0 + lane;
@@ -1468,13 +1473,80 @@ __global__ __launch_bounds__(256) void k_thread_sort(const int* __restrict__ off
                 out[b + rank] = rid;
             }
             __builtin_amdgcn_wave_barrier();
-        } else {
-            for (int x = lane; x < n; x += 64) {
-                const int mine = in[b + x];
-                int rank = 0;
-                for (int y = 0; y < n; y++) rank += (in[b + y] < mine);
-                out[b + rank] = mine;
+        } else if (lane == 0) {
+            big[1 + atomicAdd(&big[0], 1)] = c;
+        }
+    }
+}
+
+// The wide classes: one workgroup per class and pass over [lo, hi] in stretches of BIG_WORDS * 32 ids -- bits of the
+// stretch's reads, exclusive prefix of the word popcounts (sixteen words per thread, then a scan over the threads), every
+// read of the stretch to its rank.  Linear in the pool for the ranges that occur (one stretch up to 524 288 ids).
+constexpr int BIG_WORDS = 16384;
+__global__ __launch_bounds__(1024) void k_thread_sort_big(const int* __restrict__ off, const int* __restrict__ in, int* __restrict__ out,
+                                                          const int* __restrict__ big, int words) {
+    extern __shared__ unsigned s_big_raw[];
+    unsigned* bits = s_big_raw;                                  // [BIG_WORDS]
+    int* wpre = reinterpret_cast<int*>(s_big_raw + BIG_WORDS);   // [BIG_WORDS]
+    __shared__ int s_part[1024];
+    __shared__ int s_lo, s_hi, s_base;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int nbig = big[0];
+    for (int bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+        const int c = big[1 + bi];
+        const int b = off[c], n = off[c + 1] - b;
+        if (tid == 0) { s_lo = 0x7fffffff; s_hi = -1; s_base = 0; }
+        __syncthreads();
+        int lo = 0x7fffffff, hi = -1;
+        for (int x = tid; x < n; x += nt) { const int v = in[b + x]; lo = min(lo, v); hi = max(hi, v); }
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        if ((tid & 63) == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+        __syncthreads();
+        lo = s_lo; hi = s_hi;
+        const long span = (long)words * 32;                      // ids per stretch (words <= BIG_WORDS; smaller only in tests)
+        for (long c0 = lo; c0 <= hi; c0 += span) {
+            const long c1 = c0 + span;                           // this stretch: ids [c0, c1)
+            const int nw = (int)(((c1 <= hi ? c1 - 1 : (long)hi) - c0) >> 5) + 1;
+            const int base = s_base;                             // reads of the class in the stretches before this one (written after the last barrier of a stretch, read before its first)
+            for (int k = tid; k < nw; k += nt) bits[k] = 0u;
+            __syncthreads();
+            for (int x = tid; x < n; x += nt) {
+                const long v = (long)in[b + x] - c0;
+                if (v >= 0 && v < span) atomicOr(&bits[v >> 5], 1u << (v & 31));
             }
+            __syncthreads();
+            // exclusive prefix of the word popcounts: a thread's sixteen words, then the threads
+            constexpr int PER = BIG_WORDS / 1024;
+            int mine = 0;
+#pragma unroll
+            for (int j = 0; j < PER; j++) { const int k = tid * PER + j; if (k < nw) mine += __popc(bits[k]); }
+            s_part[tid] = mine;
+            __syncthreads();
+            if (tid < 64) {
+                // 1024 partial sums: sixteen per lane of the first wavefront, then across the lanes
+                int loc[16], tot = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) { loc[j] = tot; tot += s_part[tid * 16 + j]; }
+                int incl = tot;
+                for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
+                const int excl = incl - tot;
+#pragma unroll
+                for (int j = 0; j < 16; j++) s_part[tid * 16 + j] = excl + loc[j];
+            }
+            __syncthreads();
+            {
+                int run = s_part[tid];
+#pragma unroll
+                for (int j = 0; j < PER; j++) { const int k = tid * PER + j; if (k < nw) { wpre[k] = run; run += __popc(bits[k]); } }
+            }
+            __syncthreads();
+            for (int x = tid; x < n; x += nt) {
+                const int rid = in[b + x];
+                const long v = (long)rid - c0;
+                if (v >= 0 && v < span) out[b + base + wpre[v >> 5] + __popc(bits[v >> 5] & ((1u << (v & 31)) - 1u))] = rid;
+            }
+            if (tid == nt - 1) { const int k = nw - 1; s_base = base + wpre[k] + __popc(bits[k]); }
+            __syncthreads();
         }
     }
 }
@@ -1501,6 +1573,7 @@ int init_kernels() {
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_any), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_resident), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msa<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSA_LDS);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_thread_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize, BIG_WORDS * 8);
     rc |= set_sample_attr<1, true>(); rc |= set_sample_attr<1, false>();
     rc |= set_sample_attr<2, true>(); rc |= set_sample_attr<2, false>();
     rc |= set_sample_attr<3, true>(); rc |= set_sample_attr<3, false>();
@@ -1626,7 +1699,15 @@ void launch_thread(hipStream_t st, const ThreadDev& d, int* pool_sorted) {
     hipLaunchKernelGGL((k_thread_walk<true>), dim3(blocks), dim3(256), 0, st, d);
     int sblocks = (ncls + 3) / 4;
     if (sblocks > 2048) sblocks = 2048;
-    hipLaunchKernelGGL(k_thread_sort, dim3(sblocks), dim3(256), 0, st, d.off, d.pool, pool_sorted, ncls);
+    hipLaunchKernelGGL(k_thread_sort, dim3(sblocks), dim3(256), 0, st, d.off, d.pool, pool_sorted, ncls, d.big);
+    // (no class of a region with fewer reads than a wavefront's bitmap has ids can be wide)
+    static const int big_words = [] {                          // SC_SORT_BIG_WORDS: a short stretch, so that a test reaches the second one
+        const char* e = getenv("SC_SORT_BIG_WORDS");
+        const int w = e ? atoi(e) : BIG_WORDS;
+        return w < 64 ? 64 : (w > BIG_WORDS ? BIG_WORDS : w);
+    }();
+    if (d.n_reads > SORT_WORDS * 32)
+        hipLaunchKernelGGL(k_thread_sort_big, dim3(512), dim3(1024), BIG_WORDS * 8, st, d.off, d.pool, pool_sorted, d.big, big_words);
 }
 
 }  // namespace sc

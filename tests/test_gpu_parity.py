@@ -259,6 +259,67 @@ def test_stage5_many_regions_one_gpu(tmp_path, oracle_bin):
         assert os.path.exists(os.path.join(d, "work", "3_straincall_results", "%s.fa" % roi))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("stretch_words", [0, 512])
+def test_thread_kernels_wide_classes(stretch_words, tmp_path):
+    """Deep coverage: 60 000 reads over a 300-base gene, so the reads of a class span far more ids than a wavefront's bitmap
+    holds (16 384) and the pools are put into read order by k_thread_sort_big -- with the full stretch of half a million ids,
+    and, in a child process, with stretches of 16 384 ids so that a class needs several.  Expected pools: the per-base M loop
+    (PartialOrderGraph.cpp:129-177) restated with numpy."""
+    import subprocess
+    import sys
+    if stretch_words:
+        env = dict(os.environ, SC_SORT_BIG_WORDS=str(stretch_words), SC_WIDE_CHILD="1")
+        p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "%s::test_thread_kernels_wide_classes" % os.path.abspath(__file__),
+                            "-k", "0]"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert p.returncode == 0, p.stdout.decode()[-3000:]
+        return
+    import numpy as np
+    import py_ingest_mirror as mirror
+    from rambl_amd import capi, cli, stage5, synth
+    g = synth.make_gene(77, glen=300, n_strains=4, n_reads=60000, name="wide77")
+    fa, sam = synth.write_dataset(str(tmp_path), [g])
+    pa = cli.parse_cmd_line(["-r", "wide77:1-300", "-q", "0", "-D", "1000000", "-I", "13", "-l", "70", "-t", "0.02", "-d", "0.02", "-w", "5000", fa, sam])
+    params = capi.default_params(float(pa.error_rate), float(pa.tau), float(pa.diff_rate), graph_only=True)
+    (window, reads), = cli.load_regions(pa)
+    assert len(reads) > 30000
+    with capi.Context(0, 1) as ctx:
+        h = ctx.submit(reads, params)
+        ctx.wait(h, release=False)
+        cnt, first, pool, sym = ctx.thread_tables(h)
+        ctx.lib.sc_roi_release(ctx.h, h)
+    code = np.full(256, 255, dtype=np.int64)
+    for k, ch in enumerate(sym):
+        if ch:
+            code[ch] = k
+    cls_parts, rid_parts = [], []
+    for rid in range(len(reads)):
+        i, j = reads.pos[rid], 0
+        sq = np.frombuffer(reads.seq[rid].encode("ascii"), dtype=np.uint8)
+        for op, ln in mirror.parse_cigar(reads.cigar[rid]):
+            if op == "M":
+                cls_parts.append((i + np.arange(ln)) * 8 + code[sq[j:j + ln]])
+                rid_parts.append(np.full(ln, rid, dtype=np.int64))
+                i += ln
+                j += ln
+            elif op == "I":
+                j += ln
+            elif op == "D":
+                i += ln
+    cls = np.concatenate(cls_parts)
+    rids = np.concatenate(rid_parts)
+    order = np.lexsort((rids, cls))
+    glen = len(reads.gene_seq)
+    exp_cnt = np.bincount(cls, minlength=glen * 8)
+    got_cnt = np.array(cnt[:], dtype=np.int64)
+    assert (got_cnt == exp_cnt).all()
+    got_pool = np.array(pool[:], dtype=np.int64)
+    assert got_pool.shape == rids.shape
+    assert (got_pool == rids[order]).all()                        # every pool in ascending read order
+    span = np.array([rids[order][a:b].max() - rids[order][a:b].min() for a, b in zip(np.cumsum(exp_cnt) - exp_cnt, np.cumsum(exp_cnt)) if b > a])
+    assert (span >= 16384).sum() > 100                              # the wide path was the one that ran
+
+
 @pytest.mark.parametrize("seed", [1, 3, 7, 13])
 def test_thread_kernels_class_tables(seed, tmp_path):
     """k_thread_* (row a5) against a plain restatement of the per-base M loop
