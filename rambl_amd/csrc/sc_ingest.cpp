@@ -420,6 +420,36 @@ struct sc_reads {
     int depth = 0;
 };
 
+namespace {
+// std::stable_sort on the rank's ingest threads: stretches sorted side by side, then merged pairwise (std::inplace_merge
+// keeps equal elements in order, so the result is the one a single stable sort gives).  A million reads of a deep region
+// are compared by position, CIGAR text and bases: two such sorts were half of the region's ingest.
+template <class T, class Less>
+static void stable_sort_mt(std::vector<T>& v, const Less& less) {
+    const size_t n = v.size();
+    int nt = std::min(inflate_threads(), 16);
+    while (nt > 1 && n / (size_t)nt < 65536) nt--;
+    if (nt <= 1) { std::stable_sort(v.begin(), v.end(), less); return; }
+    std::vector<size_t> cut((size_t)nt + 1);
+    for (int t = 0; t <= nt; t++) cut[(size_t)t] = n * (size_t)t / (size_t)nt;
+    {
+        std::vector<std::thread> ts;
+        for (int t = 1; t < nt; t++) ts.emplace_back([&, t] { std::stable_sort(v.begin() + (long)cut[(size_t)t], v.begin() + (long)cut[(size_t)t + 1], less); });
+        std::stable_sort(v.begin(), v.begin() + (long)cut[1], less);
+        for (auto& th : ts) th.join();
+    }
+    for (int width = 1; width < nt; width *= 2) {
+        std::vector<std::thread> ts;
+        for (int lo = 0; lo + width < nt; lo += 2 * width) {
+            const size_t b = cut[(size_t)lo], m = cut[(size_t)(lo + width)], e = cut[(size_t)std::min(lo + 2 * width, nt)];
+            ts.emplace_back([&v, &less, b, m, e] { std::inplace_merge(v.begin() + (long)b, v.begin() + (long)m, v.begin() + (long)e, less); });
+        }
+        for (auto& th : ts) th.join();
+    }
+}
+
+}  // namespace
+
 extern "C" {
 
 int sc_aln_open(const char* path, sc_aln** out) { return sc_aln_open_filtered(path, nullptr, -1, out); }
@@ -631,7 +661,7 @@ int sc_aln_load_reads(sc_aln* a, const char* gene, int p0, int p1, int mq, int r
         if (c == 0 && x.seq_len != y.seq_len) c = x.seq_len < y.seq_len ? -1 : 1;
         return c;
     };
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t i, uint32_t j) { return cmp3(kept[i], kept[j]) < 0; });
+    stable_sort_mt(order, [&](uint32_t i, uint32_t j) { return cmp3(kept[i], kept[j]) < 0; });
     std::vector<int> uid_of(nk);
     int n_uniq = 0;
     for (size_t k = 0; k < nk; k++) {
@@ -676,7 +706,7 @@ int sc_aln_load_reads(sc_aln* a, const char* gene, int p0, int p1, int mq, int r
         }
     };
     // by_name holds positions in `order`
-    std::stable_sort(by_name.begin(), by_name.end(), [&](uint32_t i, uint32_t j) { return name_cmp(kept[order[i]], kept[order[j]]) < 0; });
+    stable_sort_mt(by_name, [&](uint32_t i, uint32_t j) { return name_cmp(kept[order[i]], kept[order[j]]) < 0; });
     // distinct names, each with the uid assigned last
     std::vector<uint32_t> names;            // positions in `order`, one per distinct name (the last assignment)
     for (size_t k = 0; k < nk; k++) {
