@@ -321,6 +321,9 @@ def main():
         "one launch per level (level server, batches on shared streams)"
 
     from rambl_amd import capi, cli, samio, stage5, synth
+    # this rank's threads (the ingest threads and the library's own) onto the CPUs next to its GPU, as a launcher would with
+    # numactl: a GPU box is a two-socket host (SC_NUMA_BIND=0 leaves placement to the scheduler)
+    near_cpus = capi.host_bind(local)
 
     def fence():
         if world > 1:

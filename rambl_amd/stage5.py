@@ -315,6 +315,8 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     errors = []
+    from . import capi
+    capi.host_bind(local)          # this rank's threads next to its GPU (a two-socket host; SC_NUMA_BIND=0: leave them)
     full = strain_call(a.fasta, a.alignments, out_dir=a.out_dir, prefix=a.prefix, opts=opts, device=local,
                        streams=a.streams, dist=dist, torch_device=dev, ingest_workers=a.ingest_workers, errors=errors)
     if full is not None:

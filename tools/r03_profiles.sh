@@ -28,11 +28,14 @@ pass depth WRITE_SIZE $D || exit 1
 export SC_PROBE_ROUNDS=1 SC_PROBE_DISTINCT=25
 SC_RESIDENT=0 pass set stats python3 $repo/tools/inflight_probe.py 100 || exit 1
 SC_RESIDENT=1 pass resident stats python3 $repo/tools/inflight_probe.py 224 || exit 1
+# configs[3] without thinning (a million reads, 59 000 per class): the kernels of the set-up, k_thread_sort_big among them
+pass deep stats python3 $repo/tools/unthinned_probe.py 100000 /tmp/unthinned_prof || echo "deep pass skipped"
 cd $repo
 python3 tools/summarize_profiles.py $out/bench_stats $out/bench_FETCH_SIZE $out/bench_WRITE_SIZE $out/summary bench_config2 > $out/summary_bench.txt
 python3 tools/summarize_profiles.py $out/depth_stats $out/depth_FETCH_SIZE $out/depth_WRITE_SIZE $out/summary depth_1e8 > $out/summary_depth.txt
-for n in set resident; do f=$(find $out/${n}_stats -name '*_kernel_stats.csv' | tail -n 1); cp $f $out/summary/${n}_kernel_stats.csv; done
+for n in set resident deep; do f=$(find $out/${n}_stats -name '*_kernel_stats.csv' 2>/dev/null | tail -n 1); [ -n "$f" ] && cp $f $out/summary/${n}_kernel_stats.csv; done
+grep -h "^run \|^{" $out/deep_stats.log > $out/summary/deep_probe.txt 2>/dev/null
 cp $out/*.json $out/summary/ 2>/dev/null
 # raw traces are large: keep the summaries only
-rm -rf $out/bench_stats $out/bench_FETCH_SIZE $out/bench_WRITE_SIZE $out/depth_stats $out/depth_FETCH_SIZE $out/depth_WRITE_SIZE $out/set_stats $out/resident_stats
+rm -rf $out/bench_stats $out/bench_FETCH_SIZE $out/bench_WRITE_SIZE $out/depth_stats $out/depth_FETCH_SIZE $out/depth_WRITE_SIZE $out/set_stats $out/resident_stats $out/deep_stats
 ls -la $out/summary
