@@ -428,7 +428,12 @@ template <class T, class Less>
 static void stable_sort_mt(std::vector<T>& v, const Less& less) {
     const size_t n = v.size();
     int nt = std::min(inflate_threads(), 16);
-    while (nt > 1 && n / (size_t)nt < 65536) nt--;
+    static const size_t min_stretch = [] {          // SC_INGEST_SORT_MIN: elements worth a thread (tests lower it to reach the merges)
+        const char* e = getenv("SC_INGEST_SORT_MIN");
+        const long v = e ? atol(e) : 65536;
+        return (size_t)(v < 2 ? 2 : v);
+    }();
+    while (nt > 1 && n / (size_t)nt < min_stretch) nt--;
     if (nt <= 1) { std::stable_sort(v.begin(), v.end(), less); return; }
     std::vector<size_t> cut((size_t)nt + 1);
     for (int t = 0; t <= nt; t++) cut[(size_t)t] = n * (size_t)t / (size_t)nt;

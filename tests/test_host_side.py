@@ -28,6 +28,19 @@ def _dump_reads(args, d):
     return out, base
 
 
+def test_ingest_sorts_on_several_threads_match_oracle(tmp_path, oracle_bin):
+    """sc_aln_load_reads sorts a deep region's reads on the ingest threads (stretches sorted side by side, merged pairwise):
+    the cases of test_ingest_matches_oracle again in a child process whose stretches are 50 reads long and whose merges
+    therefore all run."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SC_INGEST_SORT_MIN="50", SC_INGEST_THREADS="5")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", os.path.abspath(__file__), "-k", "test_ingest_matches_oracle"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    assert b"12 passed" in p.stdout
+
+
 @pytest.mark.parametrize("seed", list(range(0, 12)))
 def test_ingest_matches_oracle(seed, tmp_path, oracle_bin):
     d = str(tmp_path)
