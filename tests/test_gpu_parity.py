@@ -164,6 +164,28 @@ def test_regions_in_flight_are_independent(tmp_path):
     assert texts == single
 
 
+def test_more_regions_set_up_than_mailboxes(tmp_path, monkeypatch):
+    """A resident context whose regions outnumber its mailboxes (three workgroups for eight region slots: SC_RESIDENT_SLOTS):
+    a region whose set-up is done waits in line for a mailbox, takes over the one a finished region hands on, and its
+    levels carry that mailbox's stamps.  Sixteen regions through it, each equal to its FASTA from a run of its own."""
+    from rambl_amd import capi, cli, stage5
+    prepared, single = [], []
+    for seed in (0, 2, 4, 9, 11, 13, 5, 8):
+        d = os.path.join(str(tmp_path), "s%d" % seed)
+        args = T.make_case(seed, d)
+        pa = cli.parse_cmd_line(args)
+        prepared.append((pa, cli.load_regions(pa)))
+        single.append(T.run_product(args))
+    monkeypatch.setenv("SC_RESIDENT", "1")
+    monkeypatch.setenv("SC_RESIDENT_SLOTS", "3")
+    errors = []
+    with capi.Context(0, 8) as ctx:
+        texts, stats = stage5.run_regions(ctx, prepared * 2, 8, None, errors)
+    assert errors == []
+    assert texts == single * 2
+    assert sum(s["mailbox_ms"] for s in stats) > 0                      # somebody did wait for a mailbox
+
+
 def test_unthinned_deep_coverage_no_sweeps(tmp_path, oracle_bin):
     """More than 40 000 read copies per level: the sweep count min(5000, 40000/copies) is 0
     (NonparametricClustering.cpp:160) and np_bayes_clustering degenerates; -D large keeps every read."""

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Phases of a configs[1] region's set-up (experiment build with -DSC_GRAPH_TIMING), one region at a time.
+# Final build: single-region parity sweep with traces, the precomputed large scenarios (one at a time and in flight).
 out=gpurun_out/r03v
 mkdir -p $out
-SC_PROBE_ROUNDS=6 timeout -k 10 300 python3 tools/inflight_probe.py 1 > $out/probe_g.txt 2> $out/probe_g.err || { echo "probe failed rc=$?"; tail -n 20 $out/probe_g.err; exit 1; }
-cut -c1-600 $out/probe_g.txt
-grep -E "phase|thread_" $out/probe_g.err | tail -n 22
+timeout -k 10 420 python3 tools/parity_sweep.py 60000 600 --jobs 14 > $out/sweep_single.txt 2>&1; tail -n 2 $out/sweep_single.txt
+timeout -k 10 300 python3 tools/big_expect_check.py > $out/big_single.txt 2>&1; tail -n 2 $out/big_single.txt
+timeout -k 10 300 python3 tools/big_expect_check.py --inflight 64 > $out/big_inflight.txt 2>&1; tail -n 2 $out/big_inflight.txt
