@@ -518,7 +518,7 @@ __device__ __forceinline__ void urn_chain_shadow(const LevelHdr& h, const int* s
 // run inside the level's single workgroup (k_level_sample / k_level); for levels with hundreds of thousands
 // of (strain, read) items the host runs the first two on a grid instead (k_level_copy, k_level_update) and
 // says so in LevelHdr::done.
-enum { LV_COPIES_DONE = 1, LV_ITEMS_DONE = 2 };
+enum { LV_COPIES_DONE = 1, LV_ITEMS_DONE = 2, LV_HAS_DONE = 4 };
 // The region's arrays as the batched level kernels see them: a block of device memory that does not change while the
 // region is walked, read through the constant address space -- scalar loads the compiler may repeat at will, exactly
 // like kernel arguments (which hold only a pointer to it: LevelItem).
@@ -567,6 +567,13 @@ __global__ __launch_bounds__(256) void k_level_update(JobDev job, LevelHdr h, co
     }
 }
 
+// grid, after phase 1: the level's reads are present in read_loglik from here on (what the level's own workgroup does with
+// 512 threads -- 117 rounds of two dependent loads on a level of 60 000 entries)
+__global__ __launch_bounds__(256) void k_level_has(JobDev job, LevelHdr h) {
+    const int Rn = h.e1 - h.e0;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Rn; r += gridDim.x * blockDim.x) job.has[job.ent_rid[h.e0 + r]] = 1;
+}
+
 // The per-strain parameters of the level, straight from host-mapped memory into LDS: 16-byte loads over PCIe,
 // every thread a few, one round trip.
 __device__ __forceinline__ void stage_params(const LevelHdr& h, const LevelParams* __restrict__ P, StrainParam* s_sp, int* s_copy,
@@ -609,7 +616,7 @@ __device__ __forceinline__ void phase_update(const JD& job, const LevelHdr& h, c
     const int S = h.S, K = job.K, K2 = K * K, e0 = h.e0, Rn = h.e1 - h.e0;
     const long stride = job.ll_stride;
     const bool plain_labels = !h.has_dups && !h.any_multi && !(h.done & LV_ITEMS_DONE);
-    if (!plain_labels) {
+    if (!plain_labels && !(h.done & LV_ITEMS_DONE)) {           // (k_level_update has written isnew with its items)
         // (the walk over multi-symbol labels below and in the soft update reads this; the usual level finds it on the way)
         for (int r = tid; r < Rn; r += nt) {
             const int e = e0 + r;
@@ -705,6 +712,7 @@ __device__ __forceinline__ void phase_update(const JD& job, const LevelHdr& h, c
     } else {
         if (tid < S) for (int r = 0; r < Rn; r++) item(tid, r);
     }
+    if (h.done & LV_HAS_DONE) { __syncthreads(); return; }      // (k_level_has, behind the grid's update; the barrier is the phase's)
     __syncthreads();
     for (int r = tid; r < Rn; r += nt) job.has[job.ent_rid[e0 + r]] = 1;
     __syncthreads();
@@ -1618,6 +1626,9 @@ int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, cons
         g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
         hipLaunchKernelGGL(k_level_update, dim3(g), dim3(256), 0, st, job, h, Pd);
         done |= LV_ITEMS_DONE;
+        int gh = (Rn + 255) / 256;
+        hipLaunchKernelGGL(k_level_has, dim3(gh < 1 ? 1 : (gh > 1024 ? 1024 : gh)), dim3(256), 0, st, job, h);
+        done |= LV_HAS_DONE;
     }
     return done;
 }
