@@ -42,7 +42,7 @@ void launch_edge_support(hipStream_t st, const int* out_ptr, const int* out_node
                          const int* pool_cn, const uint8_t* node_is_end, const int* edge_src, int n_edges, int sorted,
                          int* support);
 bool level_wants_grid(const JobDev& job, const LevelHdr& h);
-int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* Pd);
+int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* Pd, LevelResult* R);
 int level_kind(const LevelHdr& h);
 int level_lds_kb(const LevelHdr& h, int K);
 int level_table_capacity();
@@ -1234,7 +1234,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
             // a very large level: row copies / the single-symbol update on a grid, from a device copy of the parameters
             const size_t bytes = offsetof(LevelParams, lpt) + sizeof(double) * (size_t)S * K * K;
             HIPCHK(hipMemcpyAsync(Pd, Ph, bytes, hipMemcpyHostToDevice, st));
-            H.done = launch_level_grid(st, jd, H, Pd);
+            H.done = launch_level_grid(st, jd, H, Pd, Rd);
             sync_stream();                               // the level's kernel runs on another stream
         }
         H.seq = (ctx->resident && mslot >= 0) ? ++ctx->mail_seq[(size_t)mslot] : ++seq;     // (a mailbox keeps its own count: regions take turns on it)

@@ -518,7 +518,7 @@ __device__ __forceinline__ void urn_chain_shadow(const LevelHdr& h, const int* s
 // run inside the level's single workgroup (k_level_sample / k_level); for levels with hundreds of thousands
 // of (strain, read) items the host runs the first two on a grid instead (k_level_copy, k_level_update) and
 // says so in LevelHdr::done.
-enum { LV_COPIES_DONE = 1, LV_ITEMS_DONE = 2, LV_HAS_DONE = 4 };
+enum { LV_COPIES_DONE = 1, LV_ITEMS_DONE = 2, LV_HAS_DONE = 4, LV_HARD_DONE = 8 };
 // The region's arrays as the batched level kernels see them: a block of device memory that does not change while the
 // region is walked, read through the constant address space -- scalar loads the compiler may repeat at will, exactly
 // like kernel arguments (which hold only a pointer to it: LevelItem).
@@ -572,6 +572,99 @@ __global__ __launch_bounds__(256) void k_level_update(JobDev job, LevelHdr h, co
 __global__ __launch_bounds__(256) void k_level_has(JobDev job, LevelHdr h) {
     const int Rn = h.e1 - h.e0;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Rn; r += gridDim.x * blockDim.x) job.has[job.ent_rid[h.e0 + r]] = 1;
+}
+
+// hard_clustering (NonparametricClustering.cpp:17-125) of a level with millions of (strain, draw slot) pairs on a grid --
+// the unthinned configs[3] region has 103 such levels of 26 strains x 110 000 slots, 9-13 ms each inside ONE workgroup.
+// The same arithmetic in the same order as level_plain_body, piece by piece: the draw slots (phase_slots); a zero
+// log-likelihood for a mate not seen yet; per slot the responsibilities p_s = exp(x_s - max) / sum (strains in order);
+// per strain ONE wavefront that adds its responsibilities exactly as the workgroup's wavefronts do (lane j the slots
+// j, j + 64, ... in order, then the tree of fixed shape): bit-identical results, 100 CUs instead of one.
+__global__ __launch_bounds__(256) void k_hard_slots(JobDev job, LevelHdr h) {
+    const int e0 = h.e0, Rn = h.e1 - h.e0;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Rn; r += gridDim.x * blockDim.x) {
+        const int e = e0 + r;
+        const int rid = job.ent_rid[e], cn = job.ent_cn[e];
+        const int qb = job.ent_qoff[e];
+        const int mb = job.mate_ptr[rid], mn = job.mate_ptr[rid + 1] - mb;
+        const uint8_t code = (job.ent_lab_len[e] == 1) ? job.labels[job.ent_lab_off[e]] : (uint8_t)0xFF;
+        for (int i = 0; i < cn; i++) {
+            const int k = cn - 1 - i;
+            job.qent[qb + i] = r;
+            job.quid[qb + i] = (k < mn) ? job.mate_idx[mb + k] : -1;
+            job.qcode[qb + i] = code;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_hard_mates(JobDev job, LevelHdr h, const LevelParams* __restrict__ P) {
+    const long stride = job.ll_stride;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < h.Q; q += gridDim.x * blockDim.x) {
+        const int uid = job.quid[q];
+        // logprob(uid) inserts a zero log-likelihood for a mate not seen yet (Strain.cpp:147-150)
+        if (uid >= 0 && !job.has[uid])
+            for (int s = 0; s < h.S; s++) job.ll[(long)P->sp[s].slot * stride + uid] = 0.0;
+    }
+}
+__global__ __launch_bounds__(256) void k_hard_resp(JobDev job, LevelHdr h, const LevelParams* __restrict__ P) {
+    __shared__ int s_slot[MAXS];
+    __shared__ double s_logpri[MAXS];
+    const int S = h.S, e0 = h.e0;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) { s_slot[s] = P->sp[s].slot; s_logpri[s] = P->sp[s].logpri; }
+    __syncthreads();
+    const long stride = job.ll_stride;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < h.Q; q += gridDim.x * blockDim.x) {
+        const int rid = job.ent_rid[e0 + job.qent[q]], uid = job.quid[q];
+        if (uid >= 0) job.has[uid] = 1;                      // (every check of k_hard_mates is behind us: a kernel boundary)
+        double* col = job.tabA + q;
+        double m = -INFINITY;
+        for (int s = 0; s < S; s++) {
+            const double* row = job.ll + (long)s_slot[s] * stride;
+            double x = s_logpri[s] + row[rid];
+            if (uid >= 0) x += row[uid];
+            col[(long)s * job.qcap] = x;
+            m = fmax(m, x);
+        }
+        double norm = 0;
+        for (int s = 0; s < S; s++) norm += exp(col[(long)s * job.qcap] - m);
+        for (int s = 0; s < S; s++) {
+            double* cell = col + (long)s * job.qcap;
+            *cell = exp(*cell - m) / norm;
+        }
+    }
+}
+// one wavefront per strain (= per workgroup of 64)
+__global__ __launch_bounds__(64) void k_hard_sums(JobDev job, LevelHdr h, const LevelParams* __restrict__ P, LevelResult* __restrict__ R) {
+    const int s = blockIdx.x, lane = threadIdx.x, K = job.K, K2 = K * K, Q = h.Q;
+    const double* prow = job.tabA + (long)s * job.qcap;
+    double acc[KMAX + 1];
+#pragma unroll
+    for (int b = 0; b <= KMAX; b++) acc[b] = 0.0;
+    for (int q = lane; q < Q; q += 64) {
+        const double p = prow[q];
+        const int code = job.qcode[q];
+        acc[KMAX] += p;
+#pragma unroll
+        for (int b = 0; b < KMAX; b++) acc[b] += (code == b) ? p : 0.0;
+    }
+#pragma unroll
+    for (int b = 0; b <= KMAX; b++) {
+        double v = acc[b];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        acc[b] = v;
+    }
+    const int a = (int)job.labels[P->sp[s].lab_off];
+    // the strain's [K][K] block of the substitution histogram: zero except the row of its own symbol (every cell written
+    // once, by the lane that owns it; the sums live in lane 0)
+    double row[KMAX];
+#pragma unroll
+    for (int b = 0; b < KMAX; b++) row[b] = __shfl(acc[b], 0);
+    for (int i = lane; i < K2; i += 64) {
+        double v = 0.0;
+#pragma unroll
+        for (int b = 0; b < KMAX; b++) if (a < K && b < K && i == a * K + b) v = row[b];
+        R->subst[(long)s * K2 + i] = v;
+    }
+    if (lane == 0) R->abund[s] = acc[KMAX];
 }
 
 // The per-strain parameters of the level, straight from host-mapped memory into LDS: 16-byte loads over PCIe,
@@ -962,7 +1055,7 @@ __device__ __forceinline__ void level_plain_body(const IT& it, unsigned char* s_
     if (tid == 0) R->phase_ticks[1] = (unsigned)(wall_clock64() - wall0);
     if (upd) phase_update(job, h, l.s_sp, l.s_lab, s_tab, tid, nt);
     if (tid == 0) R->phase_ticks[2] = (unsigned)(wall_clock64() - wall0);
-    if (Rn <= 0 || S <= 0 || h.mode != MODE_HARD) { finish_level(h, R, wall0, tid); return; }
+    if (Rn <= 0 || S <= 0 || h.mode != MODE_HARD || (h.done & LV_HARD_DONE)) { finish_level(h, R, wall0, tid); return; }
     phase_slots(job, h, tid, nt);
     if (tid == 0) R->phase_ticks[3] = (unsigned)(wall_clock64() - wall0);
 
@@ -1600,11 +1693,17 @@ int level_table_capacity() { return LDS_BIG / (int)sizeof(double); }
 // in front of these launches on the same stream.  Returns the LV_* bits to pass on in LevelHdr::done.
 constexpr long GRID_ITEMS = 1L << 17;          // (strain, read) items of a level
 constexpr long GRID_COPY_WORDS = 1L << 19;     // doubles copied for new strains
+constexpr long GRID_HARD = 1L << 18;           // (strain, draw slot) pairs of a hard update
+static bool hard_on_grid(const LevelHdr& h) {
+    // (behind the grid's update only: the pieces of a level keep their order)
+    return h.mode == MODE_HARD && h.do_update && (long)h.S * (h.e1 - h.e0) > GRID_ITEMS && !h.has_dups && !h.any_multi &&
+           (long)h.S * h.Q > GRID_HARD && h.e1 > h.e0;
+}
 bool level_wants_grid(const JobDev& job, const LevelHdr& h) {
     const long items = (long)h.S * (h.e1 - h.e0);
     return (h.do_update && items > GRID_ITEMS && !h.has_dups && !h.any_multi) || (long)h.n_copy * job.n_reads > GRID_COPY_WORDS;
 }
-int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* Pd) {
+int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, const LevelParams* Pd, LevelResult* R) {
     const int S = h.S, Rn = h.e1 - h.e0;
     int done = 0;
     const bool update_on_grid = h.do_update && (long)S * Rn > GRID_ITEMS && !h.has_dups && !h.any_multi;
@@ -1629,6 +1728,15 @@ int launch_level_grid(hipStream_t st, const JobDev& job, const LevelHdr& h, cons
         int gh = (Rn + 255) / 256;
         hipLaunchKernelGGL(k_level_has, dim3(gh < 1 ? 1 : (gh > 1024 ? 1024 : gh)), dim3(256), 0, st, job, h);
         done |= LV_HAS_DONE;
+        if (hard_on_grid(h)) {
+            int gq = (h.Q + 255) / 256;
+            gq = gq < 1 ? 1 : (gq > 2048 ? 2048 : gq);
+            hipLaunchKernelGGL(k_hard_slots, dim3(gh < 1 ? 1 : (gh > 1024 ? 1024 : gh)), dim3(256), 0, st, job, h);
+            hipLaunchKernelGGL(k_hard_mates, dim3(gq), dim3(256), 0, st, job, h, Pd);
+            hipLaunchKernelGGL(k_hard_resp, dim3(gq), dim3(256), 0, st, job, h, Pd);
+            hipLaunchKernelGGL(k_hard_sums, dim3(S), dim3(64), 0, st, job, h, Pd, R);
+            done |= LV_HARD_DONE;
+        }
     }
     return done;
 }
