@@ -298,8 +298,9 @@ def main(argv=None):
     ap.add_argument("alignments", help="BAM or SAM text of the reads aligned to the seed genes")
     ap.add_argument("-o", "--out-dir", default=".")
     ap.add_argument("-p", "--prefix", default="rambl")
-    ap.add_argument("-s", "--streams", type=int, default=128, help="regions in flight per GPU")
-    ap.add_argument("-j", "--ingest-workers", type=int, default=4, help="host threads reading the alignments")
+    ap.add_argument("-s", "--streams", type=int, default=224, help="regions in flight per GPU")
+    ap.add_argument("-j", "--ingest-workers", type=int, default=4,
+                    help="host threads preparing the next regions (at most the rank's share of the host's CPUs: sc_host_plan)")
     for k, v in RAMBL_DEFAULTS.items():
         ap.add_argument("--" + k.replace("_", "-"), default=v, type=type(v))
     a = ap.parse_args(argv)
@@ -317,6 +318,7 @@ def main(argv=None):
     errors = []
     from . import capi
     capi.host_bind(local)          # this rank's threads next to its GPU (a two-socket host; SC_NUMA_BIND=0: leave them)
+    a.ingest_workers = max(1, min(a.ingest_workers, capi.host_plan(max(a.streams, 1))[2]))      # 8 ranks on 16 CPUs: one each
     full = strain_call(a.fasta, a.alignments, out_dir=a.out_dir, prefix=a.prefix, opts=opts, device=local,
                        streams=a.streams, dist=dist, torch_device=dev, ingest_workers=a.ingest_workers, errors=errors)
     if full is not None:
