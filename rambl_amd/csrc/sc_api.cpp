@@ -954,6 +954,16 @@ extern "C" long double sc_add_ones(long double a, unsigned long k) {
     if (!std::isfinite((double)a) && !(a == a && a - a == 0)) return a + (long double)k;       // inf / NaN stay what they are
     while (k > 0) {
         if (!(a >= 1)) { a += 1; k--; continue; }            // below 1 (or negative): the literal addition, at most a few times
+        {
+            // the usual case without a call into libm (this runs once per candidate and level): all k additions stay below
+            // the next power of two -- read off the x87 representation (sign + 15-bit exponent above a 64-bit mantissa)
+            union { long double v; struct { uint64_t mant; uint16_t se; } b; } top;
+            top.v = a;
+            top.b.se = (uint16_t)((top.b.se & 0x7fffu) + 1u);      // 2^e for a in [2^(e-1), 2^e)
+            top.b.mant = 0x8000000000000000ull;
+            // (a < 2^64: an ulp of at most 1, so the difference and the sum are exact)
+            if ((top.b.se & 0x7fffu) <= 16383u + 64u && top.v - a > (long double)k) return a + (long double)k;
+        }
         int e;
         (void)frexpl(a, &e);                                 // a in [2^(e-1), 2^e)
         const long double top = ldexpl(1.0L, e);
