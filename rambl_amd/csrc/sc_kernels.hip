@@ -1747,7 +1747,8 @@ int level_kind(const LevelHdr& h) {
     const int S = h.S, Q = h.Q, Rn = h.e1 - h.e0;
     const bool chain = h.mode == MODE_SAMPLE && h.n_sweeps > 0 && S > 1 && Rn > 0;
     if (!chain) return 0;
-    const bool wl = ((long)Q * chain_w_stride(S) + 16) * 4 <= (long)CHAINW_ROWS_BYTES;
+    static const bool rows_lds_allowed = !(getenv("SC_ROWS_LDS") && atoi(getenv("SC_ROWS_LDS")) == 0);     // measurements: rows in HBM everywhere
+    const bool wl = rows_lds_allowed && ((long)Q * chain_w_stride(S) + 16) * 4 <= (long)CHAINW_ROWS_BYTES;
     int nb = (S + 15) / 16;
     nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
     return 1 + 2 * (nb - 1) + (wl ? 1 : 0);
