@@ -57,6 +57,67 @@ def test_gather_world2_gloo(tmp_path):
     assert (tmp_path / "ok").read_text() == "ok"
 
 
+def test_eight_ranks_on_one_host_gloo(tmp_path):
+    """Eight ranks under torch.distributed.run on THIS host (gloo, no GPU; LOCAL_WORLD_SIZE = 8 comes from the launcher): every
+    rank keeps the records of its own shard only, plans its host threads from an eighth of the CPUs, runs stage 5 of its
+    shard through a stand-in context and the gather; rank 0 gets every region in .fai order.  The thread plans of the eight
+    ranks together stay within the host (sixteen planned threads on a 16-CPU share: sc_host_plan with the launcher's
+    LOCAL_WORLD_SIZE) and no rank's ingest spawns more OS threads than its plan."""
+    from rambl_amd import synth
+    genes = [synth.make_gene(800 + k, glen=300, n_strains=2, n_reads=120 + 40 * k, rlen=110, name="g%02d" % k) for k in range(12)]
+    fa, sam = synth.write_dataset(str(tmp_path / "data"), genes)
+    script = tmp_path / "w8.py"
+    script.write_text(textwrap.dedent('''
+        import json, os, sys
+        sys.path.insert(0, %r)
+        import torch.distributed as dist
+        from rambl_amd import capi, stage5
+        dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+        r = dist.get_rank()
+        assert os.environ["LOCAL_WORLD_SIZE"] == "8"
+        threads_before = len(os.listdir("/proc/self/task"))
+        plan16 = capi.host_plan(224, 0, 16.0)             # what this rank starts on a 16-CPU share of the host
+        plan_here = capi.host_plan(224)
+
+        class Res:
+            def __init__(self, n):
+                self.seqs, self.abundance, self.stats = ["ACGT" * n], [1.0], {}
+
+        class Ctx:                                        # stand-in for the device: a region's "strain" says how many reads it had
+            def __init__(self):
+                self.jobs = {}
+            def submit(self, reads, params):
+                self.jobs[len(self.jobs) + 1] = len(reads)
+                return len(self.jobs)
+            def wait(self, h):
+                return Res(self.jobs[h])
+
+        peak = [threads_before]
+        full = stage5.strain_call(%r, %r, out_dir=%r, prefix="w8", dist=dist, ctx=Ctx(), streams=4,
+                                  ingest_workers=max(1, min(4, plan_here[2])))
+        peak.append(len(os.listdir("/proc/self/task")))
+        open(os.path.join(%r, "rank%%d.json" %% r), "w").write(json.dumps({"plan16": plan16, "plan_here": plan_here,
+                                                                             "threads": peak, "full": full if r == 0 else None}))
+        dist.barrier()
+        dist.destroy_process_group()
+    ''' % (ROOT, fa, sam, str(tmp_path / "out"), str(tmp_path))))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                           "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)], env=env,
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    import json
+    ranks = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(8)]
+    assert all(tuple(x["plan16"]) == (1, 1, 2) for x in ranks)                    # 8 x (1 executor + 1 level server) = 16 CPUs
+    assert sum(x["plan16"][0] + x["plan16"][1] for x in ranks) <= 16
+    assert all(x["plan_here"][0] + x["plan_here"][1] <= max(2, (os.cpu_count() or 8) // 8 + 1) for x in ranks)
+    # the native reader's threads end with sc_aln_open; what is left afterwards are the rank's own (torch, gloo, the pool)
+    assert all(x["threads"][1] - x["threads"][0] <= 4 + 2 for x in ranks), [x["threads"] for x in ranks]
+    full = ranks[0]["full"]
+    names = [l[1:] for l in full.splitlines() if l.startswith(">")]
+    assert len(names) == 12 and names == sorted(names)                            # every region once, in .fai order
+    assert (tmp_path / "out" / "w8.fa").read_text() == full
+
+
 def _two_gene_dataset(d):
     from rambl_amd import synth
     genes = [synth.make_gene(700, glen=300, n_strains=2, n_reads=150, rlen=110, name="full"),
