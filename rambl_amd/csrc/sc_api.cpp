@@ -275,6 +275,14 @@ struct Ctx {
     std::thread server;
     void submit_level(const LevelRequest& rq);
     void serve_levels();
+    // Resident contexts without a level server (SC_POLL_EXEC, the default): a worker whose level is in its mailbox raises
+    // its flag and parks; the continuation threads look at the flagged workers' stamps between two fibers and while they
+    // spin for one (FiberPool::set_poll), and the thread that sees a stamp makes the region ready.  The CPU the server spent
+    // going round the stamps is an executor's.
+    bool poll_exec = false;
+    std::unique_ptr<std::atomic<uint8_t>[]> polled;      // [workers]: 1 = parked until its level's stamp arrives
+    bool poll_stamps();                                  // true: some worker is still waiting for its stamp
+    void poll_health();                                  // the heart thread, once a second: flagged workers whose workgroup has gone
     double* dU = nullptr;             // uniform stream on the device
     float* dUf = nullptr;             // fp32 copy
     // Resident level workers (k_level_resident): while regions are in flight one workgroup per slot stays on its CU and
@@ -757,6 +765,41 @@ void Ctx::resident_shutdown() {
         while (hipStreamQuery(rstream) == hipErrorNotReady && now_ms() - t0 < 10000.0) std::this_thread::sleep_for(std::chrono::microseconds(100));
     }
     gen_state = GEN_STOPPED;
+}
+bool Ctx::poll_stamps() {
+    const size_t n = workers.size();
+    bool waiting = false;
+    for (size_t i = 0; i < n; i++) {
+        if (polled[i].load(std::memory_order_acquire) != 1) continue;
+        Worker* w = workers[i].get();
+        if (__atomic_load_n(&w->Rh->seq, __ATOMIC_ACQUIRE) != w->level_want) { waiting = true; continue; }
+        uint8_t one = 1;
+        if (!polled[i].compare_exchange_strong(one, 0, std::memory_order_acq_rel)) continue;      // another thread saw it first
+        w->t_seen = now_ms();
+        w->level_state.store(2, std::memory_order_release);
+        pool->make_ready(w->fib);
+    }
+    return waiting;
+}
+void Ctx::poll_health() {
+    const size_t n = workers.size();
+    for (size_t i = 0; i < n; i++) {
+        if (polled[i].load(std::memory_order_acquire) != 1) continue;
+        Worker* w = workers[i].get();
+        const int m = w->mslot;
+        if (m < 0) continue;
+        const unsigned ms = __atomic_load_n(&mail_h[m].state, __ATOMIC_ACQUIRE);
+        const bool never = ms == 0u && now_ms() - w->t_posted > 20000.0;       // more slots than the GPU holds resident
+        if ((ms < 2u && !never) || __atomic_load_n(&w->Rh->seq, __ATOMIC_ACQUIRE) == w->level_want) continue;
+        uint8_t one = 1;
+        if (!polled[i].compare_exchange_strong(one, 0, std::memory_order_acq_rel)) continue;
+        w->level_err = never ? "the slot's resident level worker has not started within 20 s (more slots than the GPU holds resident workgroups?)"
+                     : ms == 3u ? "the slot's resident level worker received an item that was not its own"
+                                : "the slot's resident level worker has left before the level was done";
+        w->t_seen = now_ms();
+        w->level_state.store(3, std::memory_order_release);
+        pool->make_ready(w->fib);
+    }
 }
 void Ctx::submit_level(const LevelRequest& rq) {
     rq.w->level_state.store(1, std::memory_order_release);
@@ -1280,7 +1323,13 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                     if (ms == 0u && now_ms() - t_posted > 20000.0) throw HipError("the resident level worker has not started within 20 s");
                 }
             } else {
-                ctx->submit_level(LevelRequest{this, LevelItem{}, KIND_POSTED, false});
+                if (ctx->poll_exec) {
+                    level_state.store(1, std::memory_order_release);
+                    ctx->polled[(size_t)slot].store(1, std::memory_order_seq_cst);      // (level_want and the mailbox are written: an executor may look)
+                    ctx->pool->ensure_poller();
+                } else {
+                    ctx->submit_level(LevelRequest{this, LevelItem{}, KIND_POSTED, false});
+                }
                 wait_level();
             }
         } else if (ctx->workers.size() == 1) {
@@ -1811,6 +1860,13 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
     }
     int plan[3] = {1, 0, 1};
     (void)sc_host_plan(stream_count, 0, 0.0, plan);
+    {
+        // resident contexts of several regions: the executors watch the stamps themselves, and the level server's CPU is one more
+        // executor's (SC_POLL_EXEC=0: the level server as for a launch per level)
+        const char* pe = getenv("SC_POLL_EXEC");
+        ctx->poll_exec = ctx->resident && stream_count > 1 && !(pe && atoi(pe) == 0);
+        if (ctx->poll_exec && plan[1] > 0) plan[0] = std::min(plan[0] + 1, std::min(stream_count, 32));
+    }
     if (const char* e = getenv("SC_EXEC_THREADS")) { const int k = atoi(e); if (k >= 1) plan[0] = std::min(k, stream_count); }
     {
         // page-locked staging of the regions' transfers: only worth it while other regions are in flight (it is their queues
@@ -1858,8 +1914,10 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
         std::memset(ctx->mail_h, 0, nm * sizeof(Mailbox));
         std::memset(ctx->ctl_h, 0, sizeof(ResidentCtl));
         ctx->heart = std::thread([ctx] {
+            unsigned beats = 0;
             while (!ctx->heart_stop.load(std::memory_order_acquire)) {
                 __atomic_fetch_add(&ctx->ctl_h->heartbeat, 1u, __ATOMIC_RELEASE);
+                if (ctx->poll_exec && ctx->pool && (++beats % 50u) == 0) ctx->poll_health();
                 std::this_thread::sleep_for(std::chrono::milliseconds(20));
             }
         });
@@ -1873,7 +1931,12 @@ int sc_ctx_create(int device, int stream_count, sc_ctx** out) {
     if (!getenv("SC_SETUP_LIMIT") && n_long > 0) ctx->setup_limit = 2 * n_long;      // a set-up waits for the GPU part of its time
     ctx->pool.reset(new FiberPool(plan[0], [dev] { (void)hipSetDevice(dev); }, n_long));
     if (getenv("SC_SERVER_LOG")) { ctx->pool->set_diag(true); ctx->wake_hist = new std::atomic<long>[24](); ctx->t_created = now_ms(); ctx->n_fast = plan[0] - n_long; ctx->n_long = n_long; }
-    if (stream_count > 1) ctx->server = std::thread([ctx] { ctx->serve_levels(); });
+    if (ctx->poll_exec) {
+        ctx->polled.reset(new std::atomic<uint8_t>[ctx->workers.size()]());
+        ctx->pool->set_poll([ctx] { return ctx->poll_stamps(); });
+    } else if (stream_count > 1) {
+        ctx->server = std::thread([ctx] { ctx->serve_levels(); });
+    }
     ctx->fibers_left.store(stream_count, std::memory_order_release);
     for (auto& w : ctx->workers) {
         Worker* p = w.get();

@@ -191,6 +191,19 @@ public:
         all_.clear();
     }
 
+    // What the continuation threads do between two fibers and while they spin for one: the owner's way of finding out that
+    // a parked fiber may run again without a thread of its own watching for it (the completion stamps of the levels in
+    // flight).  It returns whether anything is still being waited for: a spinning thread then keeps spinning instead of
+    // going to sleep (nobody else would wake the parked fibers).  Set before any fiber is made ready; called from several
+    // threads at once.
+    void set_poll(std::function<bool()> poll) { poll_ = std::move(poll); if (max_spinners_ < 1) max_spinners_ = 1; }
+
+    // A fiber is about to park for something only the poll can see: somebody must be watching.  (Call after the thing to
+    // watch has been published.)
+    void ensure_poller() {
+        if (spinners_.load(std::memory_order_seq_cst) == 0 && sleepers_.load(std::memory_order_seq_cst) > 0) wake(cv_);
+    }
+
     // diagnostics / tests
     void set_diag(bool on) { diag_ = on; }
     // time stamp counter ticks the two kinds of executor have spent inside fibers, and how long the stretches were
@@ -226,9 +239,12 @@ private:
     // Wakes one sleeping executor.  Passing through the sleepers' mutex first: a sleeper that has announced itself and
     // checked the counters before they rose is inside wait() by the time this notifies.
     void wake(std::condition_variable& cv) {
-        { std::lock_guard<std::mutex> lk(sleep_mu_); }
+        // (a thread that is on its way to sleep polls once more with the mutex held; what it finds it makes ready itself and
+        // sees before it waits: it must not ask for the mutex again)
+        if (!holds_sleep_mu()) { std::lock_guard<std::mutex> lk(sleep_mu_); }
         cv.notify_one();
     }
+    static bool& holds_sleep_mu() { static thread_local bool h = false; return h; }
     // what a thread of this kind may take: the set-up threads take the long stretches first, the others never take them
     // when the pool is split
     bool has_work(bool lng) const {
@@ -249,6 +265,7 @@ private:
         if (on_start_) on_start_();
         void* self_sp = nullptr;
         for (;;) {
+            if (!lng && poll_) poll_();
             Fiber* f = take(lng);
             if (!f) {
                 // Nothing ready (for this kind of thread).  A rank's CPU share is a quota of CPU TIME (a GPU box hands out 16
@@ -257,15 +274,23 @@ private:
                 // up within a fraction of a microsecond); the others sleep and are woken when fibers queue up behind the spinners.
                 if (!lng && spinners_.load(std::memory_order_acquire) < max_spinners_) {
                     spinners_.fetch_add(1, std::memory_order_acq_rel);
-                    for (unsigned spins = 0; spins < 6000 && !has_work(false); spins++) __builtin_ia32_pause();
+                    bool watch = false;
+                    for (unsigned spins = 0; (spins < 6000 || watch) && !has_work(false) && !stop_.load(std::memory_order_relaxed); spins++) {
+                        if (poll_ && (spins & 7u) == 7u) watch = poll_();
+                        __builtin_ia32_pause();
+                    }
                     spinners_.fetch_sub(1, std::memory_order_acq_rel);
                     if (has_work(false)) continue;
                 }
                 std::atomic<int>& sl = lng ? long_sleepers_ : sleepers_;
                 std::unique_lock<std::mutex> lk(sleep_mu_);
                 sl.fetch_add(1, std::memory_order_seq_cst);
-                if (!has_work(lng)) {
-                    if (stop_.load()) { sl.fetch_sub(1, std::memory_order_seq_cst); return; }
+                // (with a poll: the last thread that could watch does not go to sleep while something is waited for)
+                if (stop_.load() && !has_work(lng)) { sl.fetch_sub(1, std::memory_order_seq_cst); return; }
+                holds_sleep_mu() = true;
+                const bool must_watch = !lng && poll_ && spinners_.load(std::memory_order_seq_cst) == 0 && poll_();
+                holds_sleep_mu() = false;
+                if (!has_work(lng) && !must_watch) {
                     (lng ? cv_long_ : cv_).wait_for(lk, std::chrono::milliseconds(lng ? 5 : 20));
                 }
                 sl.fetch_sub(1, std::memory_order_seq_cst);
@@ -291,6 +316,7 @@ private:
     }
 
     std::function<void()> on_start_;
+    std::function<bool()> poll_;
     std::vector<std::thread> threads_;
     std::mutex sleep_mu_;                        // the sleeping executors' (and all_'s); never held while a queue is touched
     std::condition_variable cv_, cv_long_;

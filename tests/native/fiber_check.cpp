@@ -1,6 +1,8 @@
 // CPU check of rambl_amd/csrc/sc_fiber.hpp: R regions-as-fibers on T executor threads, a "server" thread that
-// completes their levels.  Usage: fiber_check R T LEVELS.  Prints one line of counters; exit 0 when every fiber has
-// walked all its levels, no more than T fibers ever ran at once, and the process never had more than T + 2 threads.
+// completes their levels.  Usage: fiber_check R T LEVELS [TL [poll]].  Prints one line of counters; exit 0 when every fiber
+// has walked all its levels, no more than T fibers ever ran at once, and the process never had more than T + 2 threads.
+// With a fifth argument the server only STAMPS the levels (as the GPU does) and the executors find the stamps themselves
+// (FiberPool::set_poll, the way resident contexts run): a fiber raises its flag, asks for a watcher and parks.
 #include <dirent.h>
 
 #include <atomic>
@@ -28,6 +30,9 @@ static int thread_count() {
 struct Region {
     Fiber* f = nullptr;
     std::atomic<int> state{0};       // 1: level posted, 2: done
+    std::atomic<int> stamp{0};       // poll mode: the number of the last level the "device" has finished (a sequence, never reset)
+    std::atomic<int> want{0};        // poll mode: the number of the level the fiber waits for
+    std::atomic<unsigned char> flag{0};   // poll mode: parked until the stamp is seen
     long levels_done = 0;
     double acc = 0;                   // something on the fiber's stack frame must survive the migrations
 };
@@ -35,6 +40,7 @@ struct Region {
 int main(int argc, char** argv) {
     const int R = argc > 1 ? atoi(argv[1]) : 512, T = argc > 2 ? atoi(argv[2]) : 4, L = argc > 3 ? atoi(argv[3]) : 300;
     const int TL = argc > 4 ? atoi(argv[4]) : 0;            // of the T threads: those that take the `later` fibers first
+    const bool poll = argc > 5;
     std::vector<Region> regs((size_t)R);
     std::mutex mu;
     std::vector<Region*> posted;
@@ -43,12 +49,28 @@ int main(int argc, char** argv) {
     int max_threads = 0;
     {
         FiberPool pool(T, nullptr, TL);
+        if (poll)
+            pool.set_poll([&] {
+                bool waiting = false;
+                for (Region& r : regs) {
+                    if (r.flag.load(std::memory_order_acquire) != 1) continue;
+                    if (r.stamp.load(std::memory_order_acquire) != r.want.load(std::memory_order_acquire)) { waiting = true; continue; }
+                    unsigned char one = 1;
+                    if (!r.flag.compare_exchange_strong(one, 0)) continue;
+                    r.state.store(2, std::memory_order_release);
+                    pool.make_ready(r.f);
+                }
+                return waiting;
+            });
         // the level server: takes what was posted, "runs" it, makes the fiber ready again
         std::thread server([&] {
             std::vector<Region*> mine;
             while (!stop.load()) {
                 { std::lock_guard<std::mutex> lk(mu); mine.swap(posted); }
-                for (Region* r : mine) { r->state.store(2, std::memory_order_release); pool.make_ready(r->f); }
+                for (Region* r : mine) {
+                    if (poll) { r->stamp.store(r->want.load(std::memory_order_acquire), std::memory_order_release); continue; }      // the executors will see it
+                    r->state.store(2, std::memory_order_release); pool.make_ready(r->f);
+                }
                 mine.clear();
                 const int tc = thread_count();
                 if (tc > max_threads) max_threads = tc;
@@ -64,7 +86,9 @@ int main(int argc, char** argv) {
                 int caught = 0;
                 for (int lv = 0; lv < L; lv++) {
                     r->state.store(1, std::memory_order_release);
+                    r->want.store(lv + 1, std::memory_order_release);
                     { std::lock_guard<std::mutex> lk(mu); posted.push_back(r); }
+                    if (poll) { r->flag.store(1, std::memory_order_seq_cst); pool.ensure_poller(); }
                     // the protocol of the library: whoever completes the level makes the fiber ready exactly once, so the
                     // fiber parks exactly once per level -- also when the level is already done by now
                     FiberPool::park();

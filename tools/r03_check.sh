@@ -1,13 +1,14 @@
 #!/bin/bash
-# What the weight rows in HBM / L2 instead of LDS cost the chain (one region, a launch per level).
+# Executors watching the stamps: split of the 16 threads, spinners (steady state at 224 in flight).
 out=gpurun_out/r03v
 mkdir -p $out
-for v in 1 0; do
-  echo "== SC_ROWS_LDS=$v"
-  SC_ROWS_LDS=$v SC_PROBE_ROUNDS=3 timeout -k 10 200 python3 tools/inflight_probe.py 1 > $out/rows_$v.txt 2> $out/rows_$v.err || { echo failed; tail $out/rows_$v.err; exit 1; }
-  python3 - <<PY
+for cfg in "8 4" "7 4" "9 4" "8 2" "8 6" "8 4"; do
+  set -- $cfg
+  echo "== SC_EXEC_LONG=$1 SC_EXEC_SPINNERS=$2"
+  SC_EXEC_LONG=$1 SC_EXEC_SPINNERS=$2 SC_PROBE_ROUNDS=8 timeout -k 10 300 python3 tools/inflight_probe.py 224 > $out/probe_ab.txt 2> $out/probe_ab.err || { echo "probe failed rc=$?"; tail -n 20 $out/probe_ab.err; exit 1; }
+  python3 - <<'PY'
 import json
-r = json.loads(open("gpurun_out/r03v/rows_$v.txt").read().strip().splitlines()[-1])
-print({k: r[k] for k in ("reads_per_s", "cluster_ms", "level_kernel_ms", "chain_ms", "chain_mcycles")})
+r = json.loads(open("gpurun_out/r03v/probe_ab.txt").read().strip().splitlines()[-1])
+print({k: r[k] for k in ("seconds", "reads_per_s", "cu_busy_frac", "cluster_ms", "graph_ms", "place_ms", "host_us_per_level", "wake_us_per_level", "cpu_cores_used", "nr_throttled")})
 PY
 done
