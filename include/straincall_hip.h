@@ -107,7 +107,8 @@ const char* sc_roi_error(sc_ctx* ctx, int handle);
 int sc_host_bind(int device);
 
 /* Host threads a context with `stream_count` regions in flight starts: out[0] executor threads (they run the regions'
- * fibers), out[1] the level server (0 or 1), out[2] threads sc_aln_open inflates BGZF members on.  `cpus` = CPUs of the
+ * fibers), out[1] the level server (0 or 1; a context on resident level workers starts one more executor instead: its
+ * executors watch the levels' completion stamps themselves), out[2] threads sc_aln_open inflates BGZF members on.  `cpus` = CPUs of the
  * host share (0: the cgroup quota / affinity mask of the process), divided by `local_world` ranks sharing it (0: the
  * environment's LOCAL_WORLD_SIZE, as torch.distributed.run sets it) -- rambl.py's Pool(cores) (scripts/rambl.py:190-194)
  * gives every region a process; here eight ranks on one host must fit its cores.  No device needed. */
