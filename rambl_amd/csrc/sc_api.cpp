@@ -775,6 +775,14 @@ bool Ctx::poll_stamps() {
         if (__atomic_load_n(&w->Rh->seq, __ATOMIC_ACQUIRE) != w->level_want) { waiting = true; continue; }
         uint8_t one = 1;
         if (!polled[i].compare_exchange_strong(one, 0, std::memory_order_acq_rel)) continue;      // another thread saw it first
+        // The flag is this thread's now -- but is it still the flag of the level whose stamp was seen?  Another thread may
+        // have seen that stamp first, the region may have run on and be parked for its NEXT level by the time the exchange
+        // above succeeded (it then took the new level's flag).  Look again, with the flag in hand: nothing changes under it.
+        if (__atomic_load_n(&w->Rh->seq, __ATOMIC_ACQUIRE) != w->level_want) {
+            polled[i].store(1, std::memory_order_seq_cst);
+            waiting = true;
+            continue;
+        }
         w->t_seen = now_ms();
         w->level_state.store(2, std::memory_order_release);
         pool->make_ready(w->fib);
@@ -793,6 +801,15 @@ void Ctx::poll_health() {
         if ((ms < 2u && !never) || __atomic_load_n(&w->Rh->seq, __ATOMIC_ACQUIRE) == w->level_want) continue;
         uint8_t one = 1;
         if (!polled[i].compare_exchange_strong(one, 0, std::memory_order_acq_rel)) continue;
+        {   // (as in poll_stamps: with the flag in hand, is it still the level that was judged?)
+            const int m2 = w->mslot;
+            const unsigned ms2 = m2 >= 0 ? __atomic_load_n(&mail_h[m2].state, __ATOMIC_ACQUIRE) : 0u;
+            const bool never2 = ms2 == 0u && now_ms() - w->t_posted > 20000.0;
+            if (m2 != m || (ms2 < 2u && !never2) || __atomic_load_n(&w->Rh->seq, __ATOMIC_ACQUIRE) == w->level_want) {
+                polled[i].store(1, std::memory_order_seq_cst);
+                continue;
+            }
+        }
         w->level_err = never ? "the slot's resident level worker has not started within 20 s (more slots than the GPU holds resident workgroups?)"
                      : ms == 3u ? "the slot's resident level worker received an item that was not its own"
                                 : "the slot's resident level worker has left before the level was done";

@@ -57,6 +57,9 @@ int main(int argc, char** argv) {
                     if (r.stamp.load(std::memory_order_acquire) != r.want.load(std::memory_order_acquire)) { waiting = true; continue; }
                     unsigned char one = 1;
                     if (!r.flag.compare_exchange_strong(one, 0)) continue;
+                    // (the flag may by now be the one of the region's NEXT level -- another thread saw this stamp first and the
+                    // region ran on: with the flag in hand, look again)
+                    if (r.stamp.load(std::memory_order_acquire) != r.want.load(std::memory_order_acquire)) { r.flag.store(1); waiting = true; continue; }
                     r.state.store(2, std::memory_order_release);
                     pool.make_ready(r.f);
                 }
@@ -93,6 +96,7 @@ int main(int argc, char** argv) {
                     // fiber parks exactly once per level -- also when the level is already done by now
                     FiberPool::park();
                     if (r->state.load(std::memory_order_acquire) != 2) { r->levels_done = -1000000; break; }
+                    if (poll && r->stamp.load(std::memory_order_acquire) != lv + 1) { r->levels_done = -2000000; break; }      // woken before its level was done
                     local[lv & 63] += 1.0;
                     r->levels_done++;
                     // long double bookkeeping and a C++ exception thrown and caught inside the fiber, wherever it runs by now

@@ -1,14 +1,40 @@
 #!/bin/bash
-# Executors watching the stamps: split of the 16 threads, spinners (steady state at 224 in flight).
+# Seed 71150 of the in-flight sweep: alone, and among its neighbours with and without the level server.
 out=gpurun_out/r03v
 mkdir -p $out
-for cfg in "8 4" "7 4" "9 4" "8 2" "8 6" "8 4"; do
-  set -- $cfg
-  echo "== SC_EXEC_LONG=$1 SC_EXEC_SPINNERS=$2"
-  SC_EXEC_LONG=$1 SC_EXEC_SPINNERS=$2 SC_PROBE_ROUNDS=8 timeout -k 10 300 python3 tools/inflight_probe.py 224 > $out/probe_ab.txt 2> $out/probe_ab.err || { echo "probe failed rc=$?"; tail -n 20 $out/probe_ab.err; exit 1; }
-  python3 - <<'PY'
-import json
-r = json.loads(open("gpurun_out/r03v/probe_ab.txt").read().strip().splitlines()[-1])
-print({k: r[k] for k in ("seconds", "reads_per_s", "cu_busy_frac", "cluster_ms", "graph_ms", "place_ms", "host_us_per_level", "wake_us_per_level", "cpu_cores_used", "nr_throttled")})
+python3 - <<'PY' 2>&1 | tail -n 30
+import os, sys, tempfile
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import sc_testlib as T
+from rambl_amd import capi, cli, stage5
+seed = 71150
+d = tempfile.mkdtemp(prefix="one_")
+args = T.make_case(seed, d)
+exp = T.run_oracle(args, d, check=False)[0]
+got = T.run_product(args)
+print("alone (a launch per level): equal =", got == exp, len(got), len(exp))
+if got != exp:
+    g, e = got.splitlines(), exp.splitlines()
+    for i, (a, b) in enumerate(zip(g, e)):
+        if a != b:
+            print("first difference at line", i, a[:80], "|", b[:80]); break
+def inflight(poll, n=224, reps=3):
+    os.environ["SC_POLL_EXEC"] = poll
+    seeds = list(range(seed - 60, seed + n - 60))
+    prepared, exps = [], []
+    for s in seeds:
+        dd = tempfile.mkdtemp(prefix="nb%d_" % s)
+        a = T.make_case(s, dd)
+        pa = cli.parse_cmd_line(a)
+        try:
+            prepared.append((pa, cli.load_regions(pa)))
+        except Exception as ex:
+            prepared.append(stage5.RegionFailure("seed%d" % s, str(ex)))
+        exps.append(T.run_oracle(a, dd, check=False)[0] if s == seed else None)
+    for rep in range(reps):
+        with capi.Context(0, n) as ctx:
+            texts, _ = stage5.run_regions(ctx, prepared, n, None, [])
+        i = seeds.index(seed)
+        print("poll", poll, "rep", rep, "in flight: equal to oracle =", texts[i] == exps[i], "equal to alone =", texts[i] == got)
+inflight("1"); inflight("0")
 PY
-done
