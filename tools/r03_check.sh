@@ -1,40 +1,13 @@
 #!/bin/bash
-# Seed 71150 of the in-flight sweep: alone, and among its neighbours with and without the level server.
-out=gpurun_out/r03v
-mkdir -p $out
-python3 - <<'PY' 2>&1 | tail -n 30
-import os, sys, tempfile
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
-import sc_testlib as T
-from rambl_amd import capi, cli, stage5
-seed = 71150
-d = tempfile.mkdtemp(prefix="one_")
-args = T.make_case(seed, d)
-exp = T.run_oracle(args, d, check=False)[0]
-got = T.run_product(args)
-print("alone (a launch per level): equal =", got == exp, len(got), len(exp))
-if got != exp:
-    g, e = got.splitlines(), exp.splitlines()
-    for i, (a, b) in enumerate(zip(g, e)):
-        if a != b:
-            print("first difference at line", i, a[:80], "|", b[:80]); break
-def inflight(poll, n=224, reps=3):
-    os.environ["SC_POLL_EXEC"] = poll
-    seeds = list(range(seed - 60, seed + n - 60))
-    prepared, exps = [], []
-    for s in seeds:
-        dd = tempfile.mkdtemp(prefix="nb%d_" % s)
-        a = T.make_case(s, dd)
-        pa = cli.parse_cmd_line(a)
-        try:
-            prepared.append((pa, cli.load_regions(pa)))
-        except Exception as ex:
-            prepared.append(stage5.RegionFailure("seed%d" % s, str(ex)))
-        exps.append(T.run_oracle(a, dd, check=False)[0] if s == seed else None)
-    for rep in range(reps):
-        with capi.Context(0, n) as ctx:
-            texts, _ = stage5.run_regions(ctx, prepared, n, None, [])
-        i = seeds.index(seed)
-        print("poll", poll, "rep", rep, "in flight: equal to oracle =", texts[i] == exps[i], "equal to alone =", texts[i] == got)
-inflight("1"); inflight("0")
-PY
+# rocprofv3 kernel statistics of 224 regions in flight on the final build (executors watch the stamps: no level server).
+set -o pipefail
+repo=$(pwd)
+out=$repo/gpurun_out/r03p
+mkdir -p $out/summary
+cd /tmp && export TMPDIR=/tmp
+export SC_PROBE_ROUNDS=1 SC_PROBE_DISTINCT=25
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/resident_stats -- python3 $repo/tools/inflight_probe.py 224 > $out/resident_stats.log 2>&1 || { echo "failed"; tail -n 5 $out/resident_stats.log; exit 1; }
+grep -h '^{' $out/resident_stats.log | tail -n 1 > $out/summary/resident_stats.json
+f=$(find $out/resident_stats -name '*_kernel_stats.csv' | tail -n 1); cp $f $out/summary/resident_kernel_stats.csv
+rm -rf $out/resident_stats
+head -n 4 $out/summary/resident_kernel_stats.csv | cut -c1-160; cut -c1-400 $out/summary/resident_stats.json
