@@ -1,13 +1,14 @@
 #!/bin/bash
-# rocprofv3 kernel statistics of 224 regions in flight on the final build (executors watch the stamps: no level server).
-set -o pipefail
-repo=$(pwd)
-out=$repo/gpurun_out/r03p
-mkdir -p $out/summary
-cd /tmp && export TMPDIR=/tmp
-export SC_PROBE_ROUNDS=1 SC_PROBE_DISTINCT=25
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/resident_stats -- python3 $repo/tools/inflight_probe.py 224 > $out/resident_stats.log 2>&1 || { echo "failed"; tail -n 5 $out/resident_stats.log; exit 1; }
-grep -h '^{' $out/resident_stats.log | tail -n 1 > $out/summary/resident_stats.json
-f=$(find $out/resident_stats -name '*_kernel_stats.csv' | tail -n 1); cp $f $out/summary/resident_kernel_stats.csv
-rm -rf $out/resident_stats
-head -n 4 $out/summary/resident_kernel_stats.csv | cut -c1-160; cut -c1-400 $out/summary/resident_stats.json
+# Final build: more executors than the default sixteen (steady state at 224 in flight).
+out=gpurun_out/r03v
+mkdir -p $out
+for cfg in "16 8" "17 8" "18 9" "17 9"; do
+  set -- $cfg
+  echo "== SC_EXEC_THREADS=$1 SC_EXEC_LONG=$2"
+  SC_EXEC_THREADS=$1 SC_EXEC_LONG=$2 SC_PROBE_ROUNDS=8 timeout -k 10 300 python3 tools/inflight_probe.py 224 > $out/probe_ab.txt 2> $out/probe_ab.err || { echo "probe failed rc=$?"; tail -n 20 $out/probe_ab.err; exit 1; }
+  python3 - <<'PY'
+import json
+r = json.loads(open("gpurun_out/r03v/probe_ab.txt").read().strip().splitlines()[-1])
+print({k: r[k] for k in ("seconds", "reads_per_s", "cu_busy_frac", "cluster_ms", "graph_ms", "place_ms", "host_us_per_level", "wake_us_per_level", "cpu_cores_used", "nr_throttled", "throttled_ms")})
+PY
+done
