@@ -1401,6 +1401,10 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         job.stats.kind_levels[std::min(std::max(level_kind(H), 0), 16)]++;
     };
 
+    struct Cand { int parent; int node; ld abundance; };
+    std::vector<Cand> cands;                                  // buffers of the walk, reused from level to level
+    std::vector<int> first_child;
+    std::vector<HStrain> kept_buf;
     for (int level = 0; level < f.n_levels; level++) {
         const int n0 = f.level_node_ptr[level], n1 = f.level_node_ptr[level + 1];
         for (int x = n0; x < n1; x++) {
@@ -1518,7 +1522,8 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
                 ld Z = 0;
                 for (int s = 0; s < S; s++) Z += a[s];
                 const ld Zt = Z * tau;
-                std::vector<HStrain> kept;
+                std::vector<HStrain>& kept = kept_buf;               // (the walk's own: no allocation per level)
+                kept.clear();
                 for (int s = 0; s < S; s++) {
                     const ld d = post[s] - prior[s];
                     if (a[s] < Zt || d < 0.01 * A_delta_max) drop(level_strains[s], free_slots);
@@ -1558,8 +1563,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
 
         // ---- candidate extension, :473-551
         branching = false;
-        struct Cand { int parent; int node; ld abundance; };
-        std::vector<Cand> cands;
+        cands.clear();
         for (const HStrain& s : level_strains) __builtin_prefetch(&f.out_ptr[(size_t)s.node]);
         for (const HStrain& s : level_strains) {
             const int ob = f.out_ptr[(size_t)s.node];
@@ -1598,7 +1602,7 @@ void Worker::cluster(Job& job, const PoGraph& g, FlatGraph& f) {
         }
         if ((int)cands.size() > MAXS) throw ScError(SC_ERR_CAPACITY, "more than 128 candidate strains at one level");
         // materialise: the first surviving child of a parent inherits its row, the others copy it
-        std::vector<int> first_child(level_strains.size(), -1);
+        first_child.assign(level_strains.size(), -1);
         for (int c = 0; c < (int)cands.size(); c++) if (first_child[cands[c].parent] < 0) first_child[cands[c].parent] = c;
         for (size_t p = 0; p < level_strains.size(); p++) if (first_child[p] < 0) drop(level_strains[p], free_slots);
         sub_strains.clear();
